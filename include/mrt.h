@@ -1,0 +1,259 @@
+/*
+ * mrt.h -- C ABI of libmrt_hip, the MI355X (gfx950) render hot path.
+ *
+ * One fused device pass replaces the six blocking OpenCL stage helpers of the
+ * reference (uv -> view rays -> closest-hit intersections -> shader) and the
+ * host glue around them.  Everything here is plain C: pointers, sizes, PODs.
+ * No C++ types, no torch types, no exceptions cross this boundary and the
+ * library never calls exit().
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout,
+ * directory "Ray Tracing/"):
+ *   CLHelpers.hpp:17   initCL()                    -> mrt_create
+ *   CLHelpers.hpp:76   cl_uv()                     -> mrt_render_* (fused), mrt_stage_uv
+ *   CLHelpers.hpp:116  cl_ortho_viewrays()         -> mrt_render_* (fused), mrt_stage_ortho_viewrays
+ *   CLHelpers.hpp:152  cl_persp_viewrays()         -> mrt_render_* (fused), mrt_stage_persp_viewrays
+ *   CLHelpers.hpp:191  cl_intersect()              -> mrt_render_* (fused), mrt_stage_intersect
+ *   CLHelpers.hpp:239  cl_flat_shader()            -> mrt_render_* (fused), mrt_stage_flat_shader
+ *   CLHelpers.hpp:276  cl_phong_shader()           -> mrt_render_* (fused), mrt_stage_phong_shader
+ *   gfxraytrace.hpp:830 gfx::scene::render()       -> mrt_set_scene + mrt_render_rgba8
+ *   CLStructs.hpp:8-128 packed AoS structs         -> mrt_scene (SoA planes) / mrt_cl_* (AoS mirrors)
+ *
+ * Threading: one mrt_ctx may be used from one thread at a time.  Distinct
+ * contexts are independent.  All entry points return MRT_OK (0) or a negative
+ * mrt_status; mrt_last_error() gives the text of the last failure on a ctx.
+ */
+#ifndef MRT_H
+#define MRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRT_ABI_VERSION 1
+
+typedef enum mrt_status {
+    MRT_OK = 0,
+    MRT_ERR_INVALID = -1,      /* bad argument / inconsistent scene            */
+    MRT_ERR_NO_DEVICE = -2,    /* no usable HIP device                         */
+    MRT_ERR_HIP = -3,          /* a HIP runtime call failed                    */
+    MRT_ERR_NO_SCENE = -4,     /* render called before mrt_set_scene           */
+    MRT_ERR_TOO_LARGE = -5,    /* size beyond a documented limit               */
+    MRT_ERR_IO = -6,           /* file could not be read / written             */
+    MRT_ERR_PARSE = -7         /* scene file rejected (message has the reason) */
+} mrt_status;
+
+enum { MRT_PROJ_ORTHO = 0, MRT_PROJ_PERSP = 1 };
+enum { MRT_SHADER_FLAT = 0, MRT_SHADER_PHONG = 1 };
+
+/*
+ * Scene as the device sees it: camera/viewport/shader constants in FP32 (the
+ * double->float casts of gfxraytrace.hpp:727-808 already applied by the
+ * caller) and primitive data as structure-of-arrays planes.  Replaces the
+ * 144-byte AoS `object`, `light`, `phong`, `cam`, `vp` of CLStructs.hpp.
+ *
+ * Object order is "all spheres, then all triangles" (gfxraytrace.hpp:701-714);
+ * object id j < n_spheres is sphere j, otherwise triangle j - n_spheres.
+ * All pointers are borrowed for the duration of the call that receives the
+ * struct and may be freed afterwards.
+ */
+typedef struct mrt_scene {
+    float eye[3], u[3], v[3], w[3];     /* camera basis (cam, CLStructs.hpp:40)  */
+    uint32_t xres, yres;                /* image size in pixels                  */
+    float left, right, top, bottom;     /* viewport (vp, CLStructs.hpp:48)       */
+    int32_t projection;                 /* MRT_PROJ_*                            */
+    float focal;                        /* persp focal length (ignored if ortho) */
+    int32_t shader;                     /* MRT_SHADER_*                          */
+    float ka, kd, ks;                   /* Blinn-Phong coefficients              */
+    float ambient[3];                   /* ambient colour                        */
+    float background[3];                /* miss colour                           */
+
+    uint32_t n_spheres;
+    const float *sph[4];                /* planes cx, cy, cz, r      [n_spheres] */
+    const uint32_t *sph_mat;            /* material index            [n_spheres] */
+
+    uint32_t n_tris;
+    const float *tri[9];                /* planes ax,ay,az,bx,by,bz,cx,cy,cz [n_tris] */
+    const uint32_t *tri_mat;            /* material index            [n_tris]    */
+
+    uint32_t n_materials;
+    const float *mat[4];                /* planes r, g, b, shininess [n_materials] */
+
+    uint32_t n_lights;
+    const float *light[6];              /* planes x, y, z, r, g, b   [n_lights]  */
+} mrt_scene;
+
+typedef struct mrt_config {
+    int32_t device;       /* HIP device ordinal; -1 = current device            */
+    uint32_t flags;       /* MRT_FLAG_*                                         */
+} mrt_config;
+
+enum {
+    MRT_FLAG_NONE = 0,
+    /* Test every (pixel, primitive) pair with the exact arithmetic only,
+     * without the conservative edge-function prefilter.  Same pixels out;
+     * exists so the prefilter can be validated against it. */
+    MRT_FLAG_NO_PREFILTER = 1u << 0,
+    /* Count the (pixel, primitive) pairs that reach the exact test into
+     * mrt_stats.exact_tests (one atomic per wavefront; off by default). */
+    MRT_FLAG_COUNT_EXACT = 1u << 1
+};
+
+typedef struct mrt_stats {
+    double upload_ms;       /* scene H2D + per-frame setup (set_scene)          */
+    double kernel_ms;       /* device time of both render kernels (HIP events)  */
+    double trace_ms;        /* ... of the closest-hit kernel alone              */
+    double shade_ms;        /* ... of the shading kernel alone                  */
+    double download_ms;     /* D2H of the pixels (0 for device-resident output) */
+    uint64_t rays;          /* primary rays = pixels rendered                   */
+    uint64_t prim_tests;    /* rays x (n_spheres + n_tris), brute force         */
+    uint64_t exact_tests;   /* (pixel, primitive) pairs that reached the exact test (0 unless counted) */
+} mrt_stats;
+
+typedef struct mrt_ctx mrt_ctx;
+
+/* Create / destroy a context bound to one GPU.  Replaces initCL()
+ * (CLHelpers.hpp:17-74): no program build at run time, kernels are
+ * precompiled for gfx950 into the library. */
+int mrt_create(const mrt_config *cfg, mrt_ctx **out);
+void mrt_destroy(mrt_ctx *ctx);
+
+/* Text of the last error on ctx (or of the last failed mrt_create when ctx is
+ * NULL).  Never NULL. */
+const char *mrt_last_error(const mrt_ctx *ctx);
+
+/* ABI version of the loaded library (== MRT_ABI_VERSION it was built with). */
+int mrt_abi_version(void);
+
+/* Copy the scene to the GPU (SoA planes) and derive the per-frame primitive
+ * records the kernel consumes.  Replaces the to_struct() packers and VLAs of
+ * gfxraytrace.hpp:727-828. */
+int mrt_set_scene(mrt_ctx *ctx, const mrt_scene *scene);
+
+/* Render the whole frame into host memory: xres*yres RGBA8, row-major, pixel
+ * (x, y) at 4*(y*xres + x), A = 255.  Bytes are unsigned(x * 255.0f) of the
+ * shaded float colour (gfximage.hpp:46-51).  Replaces gfx::scene::render()
+ * (gfxraytrace.hpp:830-878) and the per-stage calls it makes. */
+int mrt_render_rgba8(mrt_ctx *ctx, uint8_t *host_out, mrt_stats *stats /* may be NULL */);
+
+/* As mrt_render_rgba8, additionally returning per pixel the winning object id
+ * (-1 = miss) and its ray parameter t (-1.0f for a miss), the fields
+ * intersect.t_ / intersects of CLStructs.hpp:115-128.  ids/t may be NULL. */
+int mrt_render_debug(mrt_ctx *ctx, uint8_t *host_out, int32_t *ids, float *t,
+                     mrt_stats *stats);
+
+/*
+ * Interleaved row-band partition used for multi-GPU rendering: the image is
+ * cut into bands of band_rows rows (the last may be short); band b belongs to
+ * rank b % world.  A rank's bands are stored back-to-back, in increasing b.
+ * mrt_band_rows() returns how many image rows rank owns.
+ */
+uint32_t mrt_band_rows(uint32_t yres, uint32_t band_rows, uint32_t rank, uint32_t world);
+
+/* Render only this rank's bands into DEVICE memory (dev_out, at least
+ * mrt_band_rows()*xres*4 bytes), asynchronously on hip_stream (a hipStream_t,
+ * NULL = the null stream).  Nothing is copied to the host; the caller gathers
+ * (RCCL) and synchronises.  kernel_ms in stats is filled only when
+ * stats != NULL, which makes the call wait for the kernel. */
+int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uint32_t world,
+                            void *dev_out, size_t dev_out_bytes, void *hip_stream,
+                            mrt_stats *stats);
+
+/* Host-side inverse of the band partition: scatter the gathered per-rank
+ * buffers (rank r's bytes start at gathered + r*stride_bytes) into a
+ * scanline-ordered xres*yres RGBA8 image. */
+int mrt_bands_to_image(const uint8_t *gathered, size_t stride_bytes, uint32_t xres, uint32_t yres,
+                       uint32_t band_rows, uint32_t world, uint8_t *image_out);
+
+/* ------------------------------------------------------------------------
+ * Scene files.  Same schema, validation order and error strings as the
+ * reference loader (rayson.hpp:380-638) and the conversion that follows it
+ * (gfxraytrace.hpp:645-721, camera basis in double :881-889).
+ * ---------------------------------------------------------------------- */
+typedef struct mrt_loaded_scene mrt_loaded_scene;
+
+/* Parse a scene file.  On failure returns MRT_ERR_IO / MRT_ERR_PARSE and
+ * writes the reference's message (without the `error loading scene "...": `
+ * prefix) into err (NUL-terminated, truncated to err_cap). */
+int mrt_scene_load_file(const char *path, mrt_loaded_scene **out, char *err, size_t err_cap);
+int mrt_scene_load_text(const char *json_text, size_t len, mrt_loaded_scene **out, char *err,
+                        size_t err_cap);
+/* Borrowed view valid until mrt_scene_free(). */
+const mrt_scene *mrt_scene_view(const mrt_loaded_scene *s);
+/* Values the CLI prints that are not part of mrt_scene (doubles before the
+ * float casts; light intensity is parsed but never used by the shaders). */
+typedef struct mrt_scene_info {
+    double eye[3], u[3], v[3], w[3];
+    double left, top, right, bottom;
+    double focal, ka, kd, ks;
+    uint32_t n_lights;
+    const double *light_pos;        /* [n_lights][3] */
+    const double *light_intensity;  /* [n_lights]    */
+} mrt_scene_info;
+const mrt_scene_info *mrt_scene_info_view(const mrt_loaded_scene *s);
+void mrt_scene_free(mrt_loaded_scene *s);
+
+/* 8-bit RGB PNG (no alpha) from an RGBA8 buffer, the format of
+ * gfxpng.hpp:63-86. */
+int mrt_write_png_rgb(const char *path, const uint8_t *rgba, uint32_t xres, uint32_t yres);
+
+/* ------------------------------------------------------------------------
+ * Stage-level entry points with the reference's own array-of-structs types,
+ * for callers that keep gfxraytrace.hpp's four-stage render() and only swap
+ * CLHelpers.hpp.  Layouts mirror CLStructs.hpp:8-128 (packed; float3 = 16 B).
+ * Inputs and outputs are HOST arrays owned by the caller; n may be any size
+ * (the reference's fixed 160000 global size, CLHelpers.hpp:9, is not kept).
+ * ---------------------------------------------------------------------- */
+#pragma pack(push, 1)
+typedef struct mrt_cl_float3 { float s[4]; } mrt_cl_float3;              /* cl_float3  16 B */
+typedef struct mrt_cl_float2 { float s[2]; } mrt_cl_float2;              /* cl_float2   8 B */
+typedef struct mrt_cl_rgb { float r, g, b, a; } mrt_cl_rgb;              /* rgbColor   16 B */
+typedef struct mrt_cl_light { mrt_cl_float3 location, color; float intensity, pad[3]; } mrt_cl_light; /* 48 B */
+typedef struct mrt_cl_cam { mrt_cl_float3 eye, u, v, w; } mrt_cl_cam;    /* cam        64 B */
+typedef struct mrt_cl_vp { float x_resolution, y_resolution, left, right, top, bottom, pad[2]; } mrt_cl_vp; /* 32 B */
+typedef struct mrt_cl_ray { mrt_cl_float3 origin, direction; } mrt_cl_ray; /* viewRay  32 B */
+typedef struct mrt_cl_phong { float ambient_coef, diffuse_coef, specular_coef; mrt_cl_float3 ambient_color; float pad; } mrt_cl_phong; /* 32 B */
+typedef struct mrt_cl_triangle { mrt_cl_float3 color; float shininess; mrt_cl_float3 a, b, c; float pad[3]; } mrt_cl_triangle; /* 80 B */
+typedef struct mrt_cl_circle { mrt_cl_float3 color; float shininess; mrt_cl_float3 center; float radius; float pad[2]; } mrt_cl_circle; /* 48 B */
+typedef struct mrt_cl_object { mrt_cl_triangle triObj; mrt_cl_circle circleObj; uint8_t is_triangle, is_circle, pad0, pad1; float pad[3]; } mrt_cl_object; /* 144 B */
+typedef struct mrt_cl_intersect {
+    mrt_cl_float3 location, normal;   /*  0, 16 */
+    uint8_t intersects;               /* 32     */
+    float t_;                         /* 33     */
+    float dummy2;                     /* 37     */
+    mrt_cl_float3 dummy3;             /* 41     */
+    uint8_t is_triangle, is_circle, dummy1; /* 57, 58, 59 */
+    float shininess;                  /* 60     */
+    mrt_cl_float3 color;              /* 64     */
+} mrt_cl_intersect;                   /* 80 B   */
+#pragma pack(pop)
+
+/* kernel `uv` (kernel.cl:123-128) / cl_uv (CLHelpers.hpp:76). */
+int mrt_stage_uv(mrt_ctx *ctx, const mrt_cl_float3 *positions, const mrt_cl_vp *viewport, int n,
+                 mrt_cl_float2 *uv_out);
+/* kernel `ortho_viewrays` (kernel.cl:130-138) / cl_ortho_viewrays (CLHelpers.hpp:116). */
+int mrt_stage_ortho_viewrays(mrt_ctx *ctx, const mrt_cl_cam *camera, const mrt_cl_float2 *uv, int n,
+                             mrt_cl_ray *rays_out);
+/* kernel `persp_viewrays` (kernel.cl:140-147) / cl_persp_viewrays (CLHelpers.hpp:152). */
+int mrt_stage_persp_viewrays(mrt_ctx *ctx, const mrt_cl_cam *camera, const mrt_cl_float2 *uv, int n,
+                             float focal_length, mrt_cl_ray *rays_out);
+/* kernel `intersections` (kernel.cl:305-379) / cl_intersect (CLHelpers.hpp:191):
+ * arbitrary rays against arbitrary objects, closest hit in (t_lower, t_upper). */
+int mrt_stage_intersect(mrt_ctx *ctx, const mrt_cl_object *objects, int n_objects,
+                        const mrt_cl_ray *rays, int n_rays, float t_upper_bound,
+                        float t_lower_bound, mrt_cl_intersect *out);
+/* kernel `flat_shader` (kernel.cl:381-396) / cl_flat_shader (CLHelpers.hpp:239). */
+int mrt_stage_flat_shader(mrt_ctx *ctx, const mrt_cl_intersect *xsects, int n, mrt_cl_rgb background,
+                          mrt_cl_rgb *out);
+/* kernel `phong_shader` (kernel.cl:398-445) / cl_phong_shader (CLHelpers.hpp:276). */
+int mrt_stage_phong_shader(mrt_ctx *ctx, const mrt_cl_intersect *xsects, const mrt_cl_phong *phong,
+                           int n, mrt_cl_rgb background, const mrt_cl_cam *camera,
+                           const mrt_cl_light *lights, int n_lights, mrt_cl_rgb *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRT_H */

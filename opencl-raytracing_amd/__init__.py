@@ -1,0 +1,11 @@
+"""MI355X-native render hot path: Python view of the C ABI in include/mrt.h.
+
+The product is the shared library ``libmrt_hip.so`` (HIP kernels + C ABI) and
+the ``mrraytracer`` command-line driver built from ``csrc/`` and ``host/``;
+this package only binds the ABI with ctypes for tests and benchmarks.
+"""
+from .capi import (  # noqa: F401
+    MrtError, Context, LoadedScene, Scene, Stats, lib, lib_path, band_rows, bands_to_image,
+    write_png_rgb, FLAG_NONE, FLAG_NO_PREFILTER, FLAG_COUNT_EXACT, PROJ_ORTHO, PROJ_PERSP,
+    SHADER_FLAT, SHADER_PHONG, CL_DTYPES, SceneStruct, EXPORTED_SYMBOLS,
+)

@@ -1,0 +1,383 @@
+"""ctypes binding of libmrt_hip.so (include/mrt.h).
+
+Loading is strict: if the shared library is missing or cannot be loaded the
+import of :func:`lib` raises -- there is no Python or CPU fallback for any
+entry point.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+
+FLAG_NONE = 0
+FLAG_NO_PREFILTER = 1 << 0
+FLAG_COUNT_EXACT = 1 << 1
+PROJ_ORTHO, PROJ_PERSP = 0, 1
+SHADER_FLAT, SHADER_PHONG = 0, 1
+
+# Every symbol include/mrt.h declares.
+EXPORTED_SYMBOLS = [
+    "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_abi_version", "mrt_set_scene",
+    "mrt_render_rgba8", "mrt_render_debug", "mrt_band_rows", "mrt_render_bands_device",
+    "mrt_bands_to_image", "mrt_scene_load_file", "mrt_scene_load_text", "mrt_scene_view",
+    "mrt_scene_info_view", "mrt_scene_free", "mrt_write_png_rgb", "mrt_stage_uv",
+    "mrt_stage_ortho_viewrays", "mrt_stage_persp_viewrays", "mrt_stage_intersect",
+    "mrt_stage_flat_shader", "mrt_stage_phong_shader",
+]
+
+_fp = C.POINTER(C.c_float)
+_up = C.POINTER(C.c_uint32)
+
+
+class SceneStruct(C.Structure):
+    """mrt_scene."""
+    _fields_ = [
+        ("eye", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+        ("xres", C.c_uint32), ("yres", C.c_uint32),
+        ("left", C.c_float), ("right", C.c_float), ("top", C.c_float), ("bottom", C.c_float),
+        ("projection", C.c_int32), ("focal", C.c_float), ("shader", C.c_int32),
+        ("ka", C.c_float), ("kd", C.c_float), ("ks", C.c_float),
+        ("ambient", C.c_float * 3), ("background", C.c_float * 3),
+        ("n_spheres", C.c_uint32), ("sph", _fp * 4), ("sph_mat", _up),
+        ("n_tris", C.c_uint32), ("tri", _fp * 9), ("tri_mat", _up),
+        ("n_materials", C.c_uint32), ("mat", _fp * 4),
+        ("n_lights", C.c_uint32), ("light", _fp * 6),
+    ]
+
+
+class ConfigStruct(C.Structure):
+    _fields_ = [("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    """mrt_stats."""
+    _fields_ = [
+        ("upload_ms", C.c_double), ("kernel_ms", C.c_double), ("trace_ms", C.c_double),
+        ("shade_ms", C.c_double), ("download_ms", C.c_double),
+        ("rays", C.c_uint64), ("prim_tests", C.c_uint64), ("exact_tests", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class SceneInfoStruct(C.Structure):
+    _fields_ = [
+        ("eye", C.c_double * 3), ("u", C.c_double * 3), ("v", C.c_double * 3), ("w", C.c_double * 3),
+        ("left", C.c_double), ("top", C.c_double), ("right", C.c_double), ("bottom", C.c_double),
+        ("focal", C.c_double), ("ka", C.c_double), ("kd", C.c_double), ("ks", C.c_double),
+        ("n_lights", C.c_uint32), ("light_pos", C.POINTER(C.c_double)),
+        ("light_intensity", C.POINTER(C.c_double)),
+    ]
+
+
+# numpy views of the packed AoS structs (mrt_cl_*), byte offsets as in the header.
+_f3 = (np.float32, (4,))
+CL_DTYPES = {
+    "float3": np.dtype([("s", np.float32, (4,))]),
+    "float2": np.dtype([("s", np.float32, (2,))]),
+    "rgb": np.dtype([("r", np.float32), ("g", np.float32), ("b", np.float32), ("a", np.float32)]),
+    "light": np.dtype({"names": ["location", "color", "intensity"], "formats": [_f3, _f3, np.float32],
+                       "offsets": [0, 16, 32], "itemsize": 48}),
+    "cam": np.dtype({"names": ["eye", "u", "v", "w"], "formats": [_f3] * 4, "offsets": [0, 16, 32, 48],
+                     "itemsize": 64}),
+    "vp": np.dtype({"names": ["x_resolution", "y_resolution", "left", "right", "top", "bottom"],
+                    "formats": [np.float32] * 6, "offsets": [0, 4, 8, 12, 16, 20], "itemsize": 32}),
+    "ray": np.dtype({"names": ["origin", "direction"], "formats": [_f3, _f3], "offsets": [0, 16],
+                     "itemsize": 32}),
+    "phong": np.dtype({"names": ["ambient_coef", "diffuse_coef", "specular_coef", "ambient_color"],
+                       "formats": [np.float32, np.float32, np.float32, _f3], "offsets": [0, 4, 8, 12],
+                       "itemsize": 32}),
+    "object": np.dtype({
+        "names": ["tri_color", "tri_shininess", "a", "b", "c", "sph_color", "sph_shininess", "center",
+                  "radius", "is_triangle", "is_circle"],
+        "formats": [_f3, np.float32, _f3, _f3, _f3, _f3, np.float32, _f3, np.float32, np.uint8, np.uint8],
+        "offsets": [0, 16, 20, 36, 52, 80, 96, 100, 116, 128, 129], "itemsize": 144}),
+    "intersect": np.dtype({
+        "names": ["location", "normal", "intersects", "t_", "dummy2", "is_triangle", "is_circle",
+                  "shininess", "color"],
+        "formats": [_f3, _f3, np.uint8, np.float32, np.float32, np.uint8, np.uint8, np.float32, _f3],
+        "offsets": [0, 16, 32, 33, 37, 57, 58, 60, 64], "itemsize": 80}),
+}
+
+
+class MrtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"mrt error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("MRT_HIP_LIB", PKG_DIR / "libmrt_hip.so"))
+
+
+_lib = None
+
+
+def lib():
+    """The loaded libmrt_hip.so with argument types declared.  Raises OSError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise OSError(f"{path} not found: build it with `make -C {PKG_DIR}` (hipcc, gfx950)")
+    L = C.CDLL(str(path))
+    vp = C.c_void_p
+    L.mrt_create.argtypes = [C.POINTER(ConfigStruct), C.POINTER(vp)]
+    L.mrt_destroy.argtypes = [vp]
+    L.mrt_destroy.restype = None
+    L.mrt_last_error.argtypes = [vp]
+    L.mrt_last_error.restype = C.c_char_p
+    L.mrt_set_scene.argtypes = [vp, C.POINTER(SceneStruct)]
+    L.mrt_render_rgba8.argtypes = [vp, vp, C.POINTER(Stats)]
+    L.mrt_render_debug.argtypes = [vp, vp, vp, vp, C.POINTER(Stats)]
+    L.mrt_band_rows.argtypes = [C.c_uint32] * 4
+    L.mrt_band_rows.restype = C.c_uint32
+    L.mrt_render_bands_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp,
+                                          C.POINTER(Stats)]
+    L.mrt_bands_to_image.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.mrt_scene_load_file.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.mrt_scene_load_text.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.mrt_scene_view.argtypes = [vp]
+    L.mrt_scene_view.restype = C.POINTER(SceneStruct)
+    L.mrt_scene_info_view.argtypes = [vp]
+    L.mrt_scene_info_view.restype = C.POINTER(SceneInfoStruct)
+    L.mrt_scene_free.argtypes = [vp]
+    L.mrt_scene_free.restype = None
+    L.mrt_write_png_rgb.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.mrt_stage_uv.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.mrt_stage_ortho_viewrays.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.mrt_stage_persp_viewrays.argtypes = [vp, vp, vp, C.c_int, C.c_float, vp]
+    L.mrt_stage_intersect.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, vp]
+
+    class _Rgb(C.Structure):
+        _fields_ = [("r", C.c_float), ("g", C.c_float), ("b", C.c_float), ("a", C.c_float)]
+    L._Rgb = _Rgb
+    L.mrt_stage_flat_shader.argtypes = [vp, vp, C.c_int, _Rgb, vp]
+    L.mrt_stage_phong_shader.argtypes = [vp, vp, vp, C.c_int, _Rgb, vp, vp, C.c_int, vp]
+    _lib = L
+    return L
+
+
+class Scene:
+    """Owns numpy planes and exposes them as an mrt_scene struct."""
+
+    def __init__(self, *, eye, u, v, w, xres, yres, left, right, top, bottom, projection, focal=0.0,
+                 shader=SHADER_FLAT, ka=0.0, kd=0.0, ks=0.0, ambient=(0, 0, 0), background=(0, 0, 0),
+                 sph=None, sph_mat=None, tri=None, tri_mat=None, mat=None, light=None):
+        f32 = np.float32
+        self.sph = np.ascontiguousarray(sph if sph is not None else np.zeros((4, 0)), dtype=f32)
+        self.tri = np.ascontiguousarray(tri if tri is not None else np.zeros((9, 0)), dtype=f32)
+        self.mat = np.ascontiguousarray(mat if mat is not None else np.zeros((4, 0)), dtype=f32)
+        self.light = np.ascontiguousarray(light if light is not None else np.zeros((6, 0)), dtype=f32)
+        self.sph_mat = np.ascontiguousarray(sph_mat if sph_mat is not None else np.zeros(0), dtype=np.uint32)
+        self.tri_mat = np.ascontiguousarray(tri_mat if tri_mat is not None else np.zeros(0), dtype=np.uint32)
+        assert self.sph.shape[0] == 4 and self.tri.shape[0] == 9 and self.mat.shape[0] == 4
+        assert self.light.shape[0] == 6
+        assert self.sph_mat.shape[0] == self.sph.shape[1] and self.tri_mat.shape[0] == self.tri.shape[1]
+        s = SceneStruct()
+        for name, val in (("eye", eye), ("u", u), ("v", v), ("w", w), ("ambient", ambient),
+                          ("background", background)):
+            arr = np.asarray(val, dtype=f32)
+            setattr(s, name, (C.c_float * 3)(*[float(x) for x in arr]))
+        s.xres, s.yres = int(xres), int(yres)
+        s.left, s.right, s.top, s.bottom = (float(f32(x)) for x in (left, right, top, bottom))
+        s.projection, s.focal, s.shader = int(projection), float(f32(focal)), int(shader)
+        s.ka, s.kd, s.ks = (float(f32(x)) for x in (ka, kd, ks))
+        s.n_spheres, s.n_tris = self.sph.shape[1], self.tri.shape[1]
+        s.n_materials, s.n_lights = self.mat.shape[1], self.light.shape[1]
+
+        def plane(a, k):
+            return a[k].ctypes.data_as(_fp) if a.shape[1] else C.cast(None, _fp)
+        for k in range(4):
+            s.sph[k] = plane(self.sph, k)
+            s.mat[k] = plane(self.mat, k)
+        for k in range(9):
+            s.tri[k] = plane(self.tri, k)
+        for k in range(6):
+            s.light[k] = plane(self.light, k)
+        s.sph_mat = self.sph_mat.ctypes.data_as(_up)
+        s.tri_mat = self.tri_mat.ctypes.data_as(_up)
+        self.struct = s
+
+    @classmethod
+    def from_struct(cls, st: SceneStruct) -> "Scene":
+        """Deep copy of an mrt_scene the library owns (e.g. a loaded scene's view)."""
+        def planes(ptrs, k, n):
+            return np.stack([np.ctypeslib.as_array(ptrs[i], shape=(n,)).copy() if n else np.zeros(0, np.float32)
+                             for i in range(k)]) if n else np.zeros((k, 0), np.float32)
+
+        def ids(ptr, n):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        return cls(eye=list(st.eye), u=list(st.u), v=list(st.v), w=list(st.w), xres=st.xres, yres=st.yres,
+                   left=st.left, right=st.right, top=st.top, bottom=st.bottom, projection=st.projection,
+                   focal=st.focal, shader=st.shader, ka=st.ka, kd=st.kd, ks=st.ks, ambient=list(st.ambient),
+                   background=list(st.background), sph=planes(st.sph, 4, st.n_spheres),
+                   sph_mat=ids(st.sph_mat, st.n_spheres), tri=planes(st.tri, 9, st.n_tris),
+                   tri_mat=ids(st.tri_mat, st.n_tris), mat=planes(st.mat, 4, st.n_materials),
+                   light=planes(st.light, 6, st.n_lights))
+
+    def with_resolution(self, xres, yres, left=None, right=None, top=None, bottom=None) -> "Scene":
+        st = self.struct
+        return Scene(eye=list(st.eye), u=list(st.u), v=list(st.v), w=list(st.w), xres=xres, yres=yres,
+                     left=st.left if left is None else left, right=st.right if right is None else right,
+                     top=st.top if top is None else top, bottom=st.bottom if bottom is None else bottom,
+                     projection=st.projection, focal=st.focal, shader=st.shader, ka=st.ka, kd=st.kd,
+                     ks=st.ks, ambient=list(st.ambient), background=list(st.background), sph=self.sph,
+                     sph_mat=self.sph_mat, tri=self.tri, tri_mat=self.tri_mat, mat=self.mat, light=self.light)
+
+    @property
+    def n_objects(self):
+        return self.struct.n_spheres + self.struct.n_tris
+
+
+class LoadedScene:
+    """A scene parsed by the library's own loader (mrt_scene_load_*)."""
+
+    def __init__(self, path=None, text=None):
+        L = lib()
+        handle = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        if path is not None:
+            rc = L.mrt_scene_load_file(str(path).encode(), C.byref(handle), err, len(err))
+        else:
+            data = text.encode() if isinstance(text, str) else bytes(text)
+            rc = L.mrt_scene_load_text(data, len(data), C.byref(handle), err, len(err))
+        if rc != 0:
+            raise MrtError(rc, err.value.decode(errors="replace"))
+        self._h = handle
+        self.struct = L.mrt_scene_view(handle).contents
+        self.info = L.mrt_scene_info_view(handle).contents
+
+    def copy(self) -> Scene:
+        return Scene.from_struct(self.struct)
+
+    def close(self):
+        if self._h:
+            lib().mrt_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """mrt_ctx bound to one GPU."""
+
+    def __init__(self, device=-1, flags=FLAG_NONE):
+        L = lib()
+        self._h = C.c_void_p()
+        cfg = ConfigStruct(device, flags)
+        rc = L.mrt_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise MrtError(rc, L.mrt_last_error(None).decode())
+        self.xres = self.yres = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MrtError(rc, lib().mrt_last_error(self._h).decode())
+
+    def set_scene(self, scene):
+        st = scene.struct
+        self._check(lib().mrt_set_scene(self._h, C.byref(st)))
+        self.xres, self.yres = st.xres, st.yres
+
+    def render(self, want_ids=False):
+        """Returns (rgba[y, x, 4] uint8, stats) or (rgba, ids, t, stats)."""
+        stats = Stats()
+        img = np.empty((self.yres, self.xres, 4), np.uint8)
+        if not want_ids:
+            self._check(lib().mrt_render_rgba8(self._h, img.ctypes.data, C.byref(stats)))
+            return img, stats
+        ids = np.empty((self.yres, self.xres), np.int32)
+        t = np.empty((self.yres, self.xres), np.float32)
+        self._check(lib().mrt_render_debug(self._h, img.ctypes.data, ids.ctypes.data, t.ctypes.data,
+                                           C.byref(stats)))
+        return img, ids, t, stats
+
+    def render_bands_device(self, band_rows_, rank, world, dev_ptr, nbytes, stream=0, timed=False):
+        stats = Stats() if timed else None
+        self._check(lib().mrt_render_bands_device(self._h, band_rows_, rank, world, dev_ptr, nbytes,
+                                                  stream or None, C.byref(stats) if timed else None))
+        return stats
+
+    # stage-level entry points on numpy structured arrays (CL_DTYPES)
+    def stage_uv(self, pos, vp):
+        out = np.zeros(len(pos), CL_DTYPES["float2"])
+        self._check(lib().mrt_stage_uv(self._h, pos.ctypes.data, vp.ctypes.data, len(pos), out.ctypes.data))
+        return out
+
+    def stage_viewrays(self, cam, uv, focal=None, out=None):
+        rays = np.zeros(len(uv), CL_DTYPES["ray"]) if out is None else out
+        if focal is None:
+            self._check(lib().mrt_stage_ortho_viewrays(self._h, cam.ctypes.data, uv.ctypes.data, len(uv),
+                                                       rays.ctypes.data))
+        else:
+            self._check(lib().mrt_stage_persp_viewrays(self._h, cam.ctypes.data, uv.ctypes.data, len(uv),
+                                                       float(focal), rays.ctypes.data))
+        return rays
+
+    def stage_intersect(self, objects, rays, t_upper, t_lower, out=None):
+        xs = np.zeros(len(rays), CL_DTYPES["intersect"]) if out is None else out
+        self._check(lib().mrt_stage_intersect(self._h, objects.ctypes.data if len(objects) else None,
+                                              len(objects), rays.ctypes.data, len(rays), float(t_upper),
+                                              float(t_lower), xs.ctypes.data))
+        return xs
+
+    def stage_flat(self, xs, background, out=None):
+        res = np.zeros(len(xs), CL_DTYPES["rgb"]) if out is None else out
+        L = lib()
+        self._check(L.mrt_stage_flat_shader(self._h, xs.ctypes.data, len(xs), L._Rgb(*background),
+                                            res.ctypes.data))
+        return res
+
+    def stage_phong(self, xs, phong, background, cam, lights, out=None):
+        res = np.zeros(len(xs), CL_DTYPES["rgb"]) if out is None else out
+        L = lib()
+        self._check(L.mrt_stage_phong_shader(self._h, xs.ctypes.data, phong.ctypes.data, len(xs),
+                                             L._Rgb(*background), cam.ctypes.data,
+                                             lights.ctypes.data if len(lights) else None, len(lights),
+                                             res.ctypes.data))
+        return res
+
+    def close(self):
+        if self._h:
+            lib().mrt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def band_rows(yres, rows_per_band, rank, world):
+    return int(lib().mrt_band_rows(yres, rows_per_band, rank, world))
+
+
+def bands_to_image(gathered: np.ndarray, stride_bytes, xres, yres, rows_per_band, world):
+    out = np.empty((yres, xres, 4), np.uint8)
+    g = np.ascontiguousarray(gathered, dtype=np.uint8)
+    rc = lib().mrt_bands_to_image(g.ctypes.data, stride_bytes, xres, yres, rows_per_band, world,
+                                  out.ctypes.data)
+    if rc != 0:
+        raise MrtError(rc, "mrt_bands_to_image")
+    return out
+
+
+def write_png_rgb(path, rgba: np.ndarray):
+    a = np.ascontiguousarray(rgba, dtype=np.uint8)
+    rc = lib().mrt_write_png_rgb(str(path).encode(), a.ctypes.data, a.shape[1], a.shape[0])
+    if rc != 0:
+        raise MrtError(rc, "mrt_write_png_rgb")

@@ -1,0 +1,542 @@
+// mrt_host.hip -- HIP host layer behind the C ABI (include/mrt.h).
+//
+// Replaces CLHelpers.hpp: where each reference stage helper created a
+// context, compiled kernel.cl, allocated buffers, copied in, launched with a
+// fixed 160000 work-items and copied out (CLHelpers.hpp:76-322), a context
+// here owns one stream and its device buffers for its whole life, the scene is
+// uploaded once (mrt_set_scene) and a frame is two kernel launches.
+#include "mrt.h"
+#include "mrt_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace mrt {
+template <int PROJ>
+__global__ void trace_kernel(const RenderParams p, float* t_out, int32_t* id_out, uint32_t pitch);
+template <int PROJ>
+__global__ void shade_kernel(const RenderParams p, const float* t_in, const int32_t* id_in, uint32_t pitch);
+}  // namespace mrt
+
+using mrt::RenderParams;
+
+struct mrt_ctx {
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::string err;
+
+    bool have_scene = false;
+    RenderParams params{};          // scene constants + device pointers
+    int projection = 0;
+    double upload_ms = 0.0;
+
+    // scene buffers
+    void* d_tri_filter = nullptr;
+    void* d_tri_exact = nullptr;
+    void* d_sph = nullptr;
+    void* d_sph_mat = nullptr;
+    void* d_mats = nullptr;
+    void* d_lights = nullptr;
+    // frame buffers (grown on demand)
+    float* d_t = nullptr;
+    int32_t* d_id = nullptr;
+    size_t plane_elems = 0;
+    uint32_t* d_out = nullptr;
+    size_t out_elems = 0;
+    unsigned long long* d_counter = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int fail(mrt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((ctx), MRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+void free_dev(void*& p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+template <typename T>
+int upload(mrt_ctx* ctx, void*& dst, const std::vector<T>& src) {
+    free_dev(dst);
+    size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc(&dst, bytes));
+    if (!src.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return MRT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Per-frame triangle prefilter records.
+//
+// For a pinhole camera the ray direction is affine in the pixel (px, py) and
+// the origin is fixed; for the orthographic camera it is the other way round
+// (kernel.cl:130-147 with the pixel grid of gfxraytrace.hpp:850-852).  The
+// three numerators Cramer's rule divides by the common determinant
+// (kernel.cl:187-195, :208-213) are therefore affine functions of (px, py).
+// With s the sign that makes a valid hit (t > 0) have a positive determinant,
+// a pixel can only hit if  E0 = s*U >= 0, E1 = s*V >= 0, E2 = s*(Det-U-V) >= 0
+// -- up to the rounding error of the FP32 evaluation the exact path performs.
+// That error is bounded here term by term and added to each edge's constant,
+// so the filter passes every pair the exact arithmetic can accept.  Triangles
+// whose sign cannot be decided (eye in the triangle's plane, ray parallel to
+// it) get a record that always passes.
+// ---------------------------------------------------------------------------
+struct D3 { double x, y, z; };
+inline D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline D3 operator*(D3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline D3 absv(D3 a) { return {std::fabs(a.x), std::fabs(a.y), std::fabs(a.z)}; }
+// Sum of the absolute values of the six products of a 3x3 determinant.
+inline double permabs(D3 a, D3 b, D3 c) {
+    return a.x * (b.y * c.z + b.z * c.y) + a.y * (b.x * c.z + b.z * c.x) + a.z * (b.x * c.y + b.y * c.x);
+}
+
+const float kAlways = 1e30f;
+
+void push_const_record(std::vector<float4>& rec, float c) {
+    for (int k = 0; k < 3; ++k) rec.push_back(make_float4(0.f, 0.f, c, 0.f));
+}
+
+void push_edge(std::vector<float4>& rec, double a, double b, double c, double margin, double xres,
+               double yres) {
+    double g = std::hypot(a, b);
+    double A, B, C;
+    if (g > 0.0 && std::isfinite(g)) {
+        // Unit gradient: the value is a signed distance in pixels.
+        A = a / g; B = b / g; C = (c + margin) / g + 0.0625;
+    } else if (std::isfinite(c)) {
+        A = 0; B = 0; C = (c + margin >= 0.0) ? 1.0 : -1.0;
+    } else {
+        A = 0; B = 0; C = 1.0;
+    }
+    // Rounding of the three coefficients to float and of the two fused
+    // multiply-adds (plus up to three additions along a row) in the kernel.
+    C += 16.0 * (1.0 / 16777216.0) * (std::fabs(A) * xres + std::fabs(B) * yres + std::fabs(C));
+    if (!(std::fabs(C) < 1e30)) C = (C > 0 || C != C) ? 1e30 : -1e30;
+    rec.push_back(make_float4((float)A, (float)B, (float)C, 0.f));
+}
+
+void build_filter_records(const mrt_scene& s, std::vector<float4>& rec) {
+    const double K = 32.0 / 16777216.0;   // 32 ulp(1)/2: generous per-term rounding budget
+    const double xres = s.xres, yres = s.yres;
+    // uv(px) = u0 + u1*px for 0-based pixel index px (kernel.cl:126-127 with
+    // pos = px + 1); (right-left) is a float subtraction in the reference.
+    const double ux1 = (double)(float)(s.right - s.left) / (double)(float)s.xres;
+    const double uy1 = (double)(float)(s.top - s.bottom) / (double)(float)s.yres;
+    const double ux0 = (double)s.left + 1.5 * ux1;
+    const double uy0 = (double)s.bottom + 1.5 * uy1;
+    const double mux = std::fmax(std::fabs(ux0), std::fabs(ux0 + ux1 * (xres - 1)));
+    const double muy = std::fmax(std::fabs(uy0), std::fabs(uy0 + uy1 * (yres - 1)));
+    const D3 eye{s.eye[0], s.eye[1], s.eye[2]}, cu{s.u[0], s.u[1], s.u[2]}, cv{s.v[0], s.v[1], s.v[2]},
+        cw{s.w[0], s.w[1], s.w[2]};
+    const bool persp = s.projection == MRT_PROJ_PERSP;
+    const double f = s.focal;
+    // Affine pixel dependence: persp direction / ortho origin = V0 + Vx*px + Vy*py.
+    const D3 Vx = cu * ux1, Vy = cv * uy1;
+    const D3 V0 = persp ? (cw * (-f) + cu * ux0 + cv * uy0) : (cu * ux0 + cv * uy0);
+    const D3 vabs = persp ? (absv(cw) * f + absv(cu) * mux + absv(cv) * muy) : (absv(cu) * mux + absv(cv) * muy);
+    const D3 dortho = cw * (-1.0);
+
+    rec.clear();
+    rec.reserve(((size_t)s.n_tris + mrt::kChunkTris) * 3);
+    for (uint32_t k = 0; k < s.n_tris; ++k) {
+        const D3 a{s.tri[0][k], s.tri[1][k], s.tri[2][k]};
+        const D3 b{s.tri[3][k], s.tri[4][k], s.tri[5][k]};
+        const D3 c{s.tri[6][k], s.tri[7][k], s.tri[8][k]};
+        const D3 s1 = a - b, s2 = a - c;
+        const D3 n = cross(s1, s2);
+        if (persp) {
+            const D3 sol = a - eye;
+            const double T = dot(sol, n);
+            const double dT = K * permabs(absv(s1), absv(s2), absv(sol));
+            if (!(std::fabs(T) > dT)) { push_const_record(rec, kAlways); continue; }
+            const double sg = T > 0 ? 1.0 : -1.0;
+            const D3 P0 = cross(sol, s2), P1 = cross(s1, sol);
+            const D3 P2 = n - P0 - P1;
+            const double dU = K * permabs(absv(sol), absv(s2), vabs);
+            const double dV = K * permabs(absv(s1), absv(sol), vabs);
+            const double dD = K * permabs(absv(s1), absv(s2), vabs);
+            const double maxD = dot(absv(n), vabs);
+            const double m2 = dU + dV + 2 * dD + K * maxD;
+            push_edge(rec, sg * dot(P0, Vx), sg * dot(P0, Vy), sg * dot(P0, V0), dU, xres, yres);
+            push_edge(rec, sg * dot(P1, Vx), sg * dot(P1, Vy), sg * dot(P1, V0), dV, xres, yres);
+            push_edge(rec, sg * dot(P2, Vx), sg * dot(P2, Vy), sg * dot(P2, V0), m2, xres, yres);
+        } else {
+            const D3 d = dortho;
+            const double Det = dot(d, n);
+            const double dD = K * permabs(absv(s1), absv(s2), absv(d));
+            if (!(std::fabs(Det) > dD)) { push_const_record(rec, kAlways); continue; }
+            const double sg = Det > 0 ? 1.0 : -1.0;
+            const D3 solabs = absv(a) + vabs;
+            const D3 Q0 = cross(s2, d), Q1 = cross(d, s1);
+            const D3 a0 = a - V0;   // sol = a0 - Vx*px - Vy*py
+            const double dU = K * permabs(solabs, absv(s2), absv(d));
+            const double dV = K * permabs(absv(s1), solabs, absv(d));
+            const double m2 = dU + dV + 2 * dD + K * std::fabs(Det);
+            const double u0 = dot(a0, Q0), ux = -dot(Vx, Q0), uy = -dot(Vy, Q0);
+            const double v0 = dot(a0, Q1), vx = -dot(Vx, Q1), vy = -dot(Vy, Q1);
+            push_edge(rec, sg * ux, sg * uy, sg * u0, dU, xres, yres);
+            push_edge(rec, sg * vx, sg * vy, sg * v0, dV, xres, yres);
+            push_edge(rec, sg * (-ux - vx), sg * (-uy - vy), sg * (Det - u0 - v0), m2, xres, yres);
+        }
+    }
+    // Pad to whole chunks with records no pixel passes.
+    while ((rec.size() / 3) % mrt::kChunkTris != 0) push_const_record(rec, -kAlways);
+}
+
+int check_scene(mrt_ctx* ctx, const mrt_scene* s) {
+    if (!s) return fail(ctx, MRT_ERR_INVALID, "scene is NULL");
+    if (s->xres == 0 || s->yres == 0) return fail(ctx, MRT_ERR_INVALID, "resolution must be positive");
+    if (s->xres > 65536u || s->yres > 65536u) return fail(ctx, MRT_ERR_TOO_LARGE, "resolution above 65536");
+    if (s->projection != MRT_PROJ_ORTHO && s->projection != MRT_PROJ_PERSP)
+        return fail(ctx, MRT_ERR_INVALID, "unknown projection");
+    if (s->shader != MRT_SHADER_FLAT && s->shader != MRT_SHADER_PHONG)
+        return fail(ctx, MRT_ERR_INVALID, "unknown shader");
+    if ((uint64_t)s->n_spheres + s->n_tris > 0x7FFFFFFFull) return fail(ctx, MRT_ERR_TOO_LARGE, "too many objects");
+    if (s->n_spheres) {
+        for (int k = 0; k < 4; ++k) if (!s->sph[k]) return fail(ctx, MRT_ERR_INVALID, "sphere plane is NULL");
+        if (!s->sph_mat) return fail(ctx, MRT_ERR_INVALID, "sph_mat is NULL");
+    }
+    if (s->n_tris) {
+        for (int k = 0; k < 9; ++k) if (!s->tri[k]) return fail(ctx, MRT_ERR_INVALID, "triangle plane is NULL");
+        if (!s->tri_mat) return fail(ctx, MRT_ERR_INVALID, "tri_mat is NULL");
+    }
+    if (s->n_materials) for (int k = 0; k < 4; ++k) if (!s->mat[k]) return fail(ctx, MRT_ERR_INVALID, "material plane is NULL");
+    if (s->n_lights) for (int k = 0; k < 6; ++k) if (!s->light[k]) return fail(ctx, MRT_ERR_INVALID, "light plane is NULL");
+    for (uint32_t k = 0; k < s->n_spheres; ++k)
+        if (s->sph_mat[k] >= s->n_materials) return fail(ctx, MRT_ERR_INVALID, "sphere material index out of range");
+    for (uint32_t k = 0; k < s->n_tris; ++k)
+        if (s->tri_mat[k] >= s->n_materials) return fail(ctx, MRT_ERR_INVALID, "triangle material index out of range");
+    return MRT_OK;
+}
+
+int ensure_planes(mrt_ctx* ctx, size_t elems) {
+    if (elems <= ctx->plane_elems) return MRT_OK;
+    if (ctx->d_t) { (void)hipFree(ctx->d_t); ctx->d_t = nullptr; }
+    if (ctx->d_id) { (void)hipFree(ctx->d_id); ctx->d_id = nullptr; }
+    ctx->plane_elems = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_t, elems * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_id, elems * sizeof(int32_t)));
+    ctx->plane_elems = elems;
+    return MRT_OK;
+}
+
+int ensure_out(mrt_ctx* ctx, size_t elems) {
+    if (elems <= ctx->out_elems) return MRT_OK;
+    if (ctx->d_out) { (void)hipFree(ctx->d_out); ctx->d_out = nullptr; }
+    ctx->out_elems = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_out, elems * sizeof(uint32_t)));
+    ctx->out_elems = elems;
+    return MRT_OK;
+}
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// Enqueue both kernels for this rank's rows on `stream`.
+int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world, uint32_t* dev_out,
+                 hipStream_t stream, bool timed) {
+    RenderParams p = ctx->params;
+    p.band_rows = band_rows;
+    p.rank = rank;
+    p.world = world;
+    p.local_rows = mrt_band_rows(p.yres, band_rows, rank, world);
+    p.out = dev_out;
+    p.flags = ctx->flags;
+    p.exact_counter = (ctx->flags & MRT_FLAG_COUNT_EXACT) ? ctx->d_counter : nullptr;
+    if (p.local_rows == 0) {
+        if (timed) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+        }
+        return MRT_OK;
+    }
+    const uint32_t pitch = round_up(p.xres, mrt::kBlockTileX);
+    const uint32_t prow = round_up(p.local_rows, mrt::kBlockTileY);
+    int rc = ensure_planes(ctx, (size_t)pitch * prow);
+    if (rc != MRT_OK) return rc;
+    if (p.exact_counter) HIP_TRY(ctx, hipMemsetAsync(p.exact_counter, 0, sizeof(unsigned long long), stream));
+
+    const dim3 tgrid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY);
+    const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
+    if (ctx->projection == MRT_PROJ_PERSP)
+        hipLaunchKernelGGL(mrt::trace_kernel<MRT_PROJ_PERSP>, tgrid, dim3(mrt::kBlockThreads), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+    else
+        hipLaunchKernelGGL(mrt::trace_kernel<MRT_PROJ_ORTHO>, tgrid, dim3(mrt::kBlockThreads), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+    HIP_TRY(ctx, hipGetLastError());
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+    if (ctx->projection == MRT_PROJ_PERSP)
+        hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_PERSP>, sgrid, dim3(256), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+    else
+        hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_ORTHO>, sgrid, dim3(256), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+    HIP_TRY(ctx, hipGetLastError());
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+    return MRT_OK;
+}
+
+int fill_stats(mrt_ctx* ctx, mrt_stats* st, uint32_t rows) {
+    if (!st) return MRT_OK;
+    float a = 0.f, b = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]));
+    st->upload_ms = ctx->upload_ms;
+    st->trace_ms = a;
+    st->shade_ms = b;
+    st->kernel_ms = (double)a + (double)b;
+    st->rays = (uint64_t)rows * ctx->params.xres;
+    st->prim_tests = st->rays * ((uint64_t)ctx->params.n_sph + ctx->params.n_tri);
+    st->exact_tests = 0;
+    if (ctx->flags & MRT_FLAG_COUNT_EXACT) {
+        unsigned long long c = 0;
+        HIP_TRY(ctx, hipMemcpy(&c, ctx->d_counter, sizeof c, hipMemcpyDeviceToHost));
+        st->exact_tests = c;
+    }
+    return MRT_OK;
+}
+
+}  // namespace
+
+// Shared with mrt_stages.hip (not part of the public ABI).
+extern "C" int mrt_stage_set_error_(mrt_ctx* ctx, int code, const char* msg) { return fail(ctx, code, msg ? msg : ""); }
+extern "C" int mrt_stage_device_(const mrt_ctx* ctx) { return ctx ? ctx->device : 0; }
+
+extern "C" {
+
+int mrt_abi_version(void) { return MRT_ABI_VERSION; }
+
+const char* mrt_last_error(const mrt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int mrt_create(const mrt_config* cfg, mrt_ctx** out) {
+    if (!out) return fail(nullptr, MRT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, MRT_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    int dev = cfg ? cfg->device : -1;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= count) return fail(nullptr, MRT_ERR_NO_DEVICE, "device ordinal out of range");
+    mrt_ctx* ctx = new mrt_ctx();
+    ctx->device = dev;
+    ctx->flags = cfg ? cfg->flags : 0;
+    auto bail = [&](const char* what, hipError_t err) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+        mrt_destroy(ctx);
+        return fail(nullptr, MRT_ERR_HIP, msg);
+    };
+    if ((e = hipSetDevice(dev)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (int k = 0; k < 3; ++k)
+        if ((e = hipEventCreate(&ctx->ev[k])) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc((void**)&ctx->d_counter, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    *out = ctx;
+    return MRT_OK;
+}
+
+void mrt_destroy(mrt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_dev(ctx->d_tri_filter); free_dev(ctx->d_tri_exact); free_dev(ctx->d_sph);
+    free_dev(ctx->d_sph_mat); free_dev(ctx->d_mats); free_dev(ctx->d_lights);
+    if (ctx->d_t) (void)hipFree(ctx->d_t);
+    if (ctx->d_id) (void)hipFree(ctx->d_id);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->d_counter) (void)hipFree(ctx->d_counter);
+    for (int k = 0; k < 3; ++k) if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
+    if (!ctx) return MRT_ERR_INVALID;
+    int rc = check_scene(ctx, s);
+    if (rc != MRT_OK) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    ctx->have_scene = false;
+
+    std::vector<float4> filt;
+    build_filter_records(*s, filt);
+    std::vector<float4> exact((size_t)s->n_tris * 3);
+    for (uint32_t k = 0; k < s->n_tris; ++k) {
+        float mbits;
+        uint32_t m = s->tri_mat[k];
+        std::memcpy(&mbits, &m, 4);
+        exact[3 * (size_t)k + 0] = make_float4(s->tri[0][k], s->tri[1][k], s->tri[2][k], mbits);
+        exact[3 * (size_t)k + 1] = make_float4(s->tri[3][k], s->tri[4][k], s->tri[5][k], 0.f);
+        exact[3 * (size_t)k + 2] = make_float4(s->tri[6][k], s->tri[7][k], s->tri[8][k], 0.f);
+    }
+    std::vector<float4> sph(s->n_spheres);
+    std::vector<uint32_t> sph_mat(s->n_spheres);
+    for (uint32_t k = 0; k < s->n_spheres; ++k) {
+        sph[k] = make_float4(s->sph[0][k], s->sph[1][k], s->sph[2][k], s->sph[3][k]);
+        sph_mat[k] = s->sph_mat[k];
+    }
+    std::vector<float4> mats(s->n_materials);
+    for (uint32_t k = 0; k < s->n_materials; ++k)
+        mats[k] = make_float4(s->mat[0][k], s->mat[1][k], s->mat[2][k], s->mat[3][k]);
+    std::vector<float4> lights((size_t)s->n_lights * 2);
+    for (uint32_t k = 0; k < s->n_lights; ++k) {
+        lights[2 * (size_t)k] = make_float4(s->light[0][k], s->light[1][k], s->light[2][k], 0.f);
+        lights[2 * (size_t)k + 1] = make_float4(s->light[3][k], s->light[4][k], s->light[5][k], 0.f);
+    }
+
+    if ((rc = upload(ctx, ctx->d_tri_filter, filt)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_tri_exact, exact)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_sph, sph)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_sph_mat, sph_mat)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_mats, mats)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_lights, lights)) != MRT_OK) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    // The staging vectors above are pageable and die with this call.
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->upload_ms = ms;
+
+    RenderParams& p = ctx->params;
+    std::memset(&p, 0, sizeof p);
+    for (int k = 0; k < 3; ++k) {
+        p.eye[k] = s->eye[k]; p.u[k] = s->u[k]; p.v[k] = s->v[k]; p.w[k] = s->w[k];
+        p.amb[k] = s->ambient[k]; p.bg[k] = s->background[k];
+    }
+    p.left = s->left; p.right = s->right; p.top = s->top; p.bottom = s->bottom;
+    // viewport::to_struct (gfxraytrace.hpp:736-740) stores the resolution as floats.
+    p.xres_f = (float)s->xres; p.yres_f = (float)s->yres;
+    p.focal = s->focal;
+    p.ka = s->ka; p.kd = s->kd; p.ks = s->ks;
+    p.shader = s->shader;
+    p.xres = s->xres; p.yres = s->yres;
+    p.n_sph = s->n_spheres; p.n_tri = s->n_tris;
+    p.n_tri_padded = (uint32_t)(filt.size() / 3);
+    p.n_lights = s->n_lights;
+    p.tri_filter = (const float4*)ctx->d_tri_filter;
+    p.tri_exact = (const float4*)ctx->d_tri_exact;
+    p.sph = (const float4*)ctx->d_sph;
+    p.sph_mat = (const uint32_t*)ctx->d_sph_mat;
+    p.mats = (const float4*)ctx->d_mats;
+    p.lights = (const float4*)ctx->d_lights;
+    ctx->projection = s->projection;
+    ctx->have_scene = true;
+    return MRT_OK;
+}
+
+uint32_t mrt_band_rows(uint32_t yres, uint32_t band_rows, uint32_t rank, uint32_t world) {
+    if (band_rows == 0 || world == 0 || rank >= world) return 0;
+    const uint64_t n_bands = ((uint64_t)yres + band_rows - 1) / band_rows;
+    if (n_bands <= rank) return 0;
+    const uint64_t mine = (n_bands - rank + world - 1) / world;     // bands rank, rank+world, ...
+    uint64_t rows = mine * band_rows;
+    const uint64_t last_band = n_bands - 1;
+    if (last_band % world == rank) rows -= n_bands * band_rows - yres;   // the short last band is mine
+    return (uint32_t)rows;
+}
+
+int mrt_render_bands_device(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world,
+                            void* dev_out, size_t dev_out_bytes, void* hip_stream, mrt_stats* stats) {
+    if (!ctx) return MRT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
+    if (band_rows == 0 || world == 0 || rank >= world) return fail(ctx, MRT_ERR_INVALID, "bad band partition");
+    const uint32_t rows = mrt_band_rows(ctx->params.yres, band_rows, rank, world);
+    const size_t need = (size_t)rows * ctx->params.xres * 4;
+    if (need && !dev_out) return fail(ctx, MRT_ERR_INVALID, "dev_out is NULL");
+    if (dev_out_bytes < need) return fail(ctx, MRT_ERR_INVALID, "dev_out too small for this rank's rows");
+    if (((uintptr_t)dev_out & 3u) != 0) return fail(ctx, MRT_ERR_INVALID, "dev_out must be 4-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int rc = launch_frame(ctx, band_rows, rank, world, (uint32_t*)dev_out, stream, stats != nullptr);
+    if (rc != MRT_OK) return rc;
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
+        rc = fill_stats(ctx, stats, rows);
+    }
+    return rc;
+}
+
+int mrt_render_debug(mrt_ctx* ctx, uint8_t* host_out, int32_t* ids, float* t, mrt_stats* stats) {
+    if (!ctx) return MRT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
+    if (!host_out && !ids && !t) return fail(ctx, MRT_ERR_INVALID, "no output requested");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t xres = ctx->params.xres, yres = ctx->params.yres;
+    const size_t npx = (size_t)xres * yres;
+    int rc = ensure_out(ctx, npx);
+    if (rc != MRT_OK) return rc;
+    rc = launch_frame(ctx, yres, 0, 1, ctx->d_out, ctx->stream, true);
+    if (rc != MRT_OK) return rc;
+    mrt_stats local;
+    std::memset(&local, 0, sizeof local);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
+    rc = fill_stats(ctx, &local, yres);
+    if (rc != MRT_OK) return rc;
+    hipEvent_t d0, d1;
+    HIP_TRY(ctx, hipEventCreate(&d0));
+    HIP_TRY(ctx, hipEventCreate(&d1));
+    (void)hipEventRecord(d0, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (host_out) e = hipMemcpyAsync(host_out, ctx->d_out, npx * 4, hipMemcpyDeviceToHost, ctx->stream);
+    const uint32_t pitch = round_up(xres, mrt::kBlockTileX);
+    if (e == hipSuccess && ids)
+        e = hipMemcpy2DAsync(ids, (size_t)xres * 4, ctx->d_id, (size_t)pitch * 4, (size_t)xres * 4, yres, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && t)
+        e = hipMemcpy2DAsync(t, (size_t)xres * 4, ctx->d_t, (size_t)pitch * 4, (size_t)xres * 4, yres, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipEventRecord(d1, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    float dms = 0.f;
+    if (e == hipSuccess) (void)hipEventElapsedTime(&dms, d0, d1);
+    (void)hipEventDestroy(d0);
+    (void)hipEventDestroy(d1);
+    if (e != hipSuccess) return fail(ctx, MRT_ERR_HIP, std::string("download: ") + hipGetErrorString(e));
+    local.download_ms = dms;
+    if (stats) *stats = local;
+    return MRT_OK;
+}
+
+int mrt_render_rgba8(mrt_ctx* ctx, uint8_t* host_out, mrt_stats* stats) {
+    if (!ctx) return MRT_ERR_INVALID;
+    if (!host_out) return fail(ctx, MRT_ERR_INVALID, "host_out is NULL");
+    return mrt_render_debug(ctx, host_out, nullptr, nullptr, stats);
+}
+
+int mrt_bands_to_image(const uint8_t* gathered, size_t stride_bytes, uint32_t xres, uint32_t yres,
+                       uint32_t band_rows, uint32_t world, uint8_t* image_out) {
+    if (!gathered || !image_out || band_rows == 0 || world == 0 || xres == 0) return MRT_ERR_INVALID;
+    const size_t line = (size_t)xres * 4;
+    for (uint32_t r = 0; r < world; ++r)
+        if ((size_t)mrt_band_rows(yres, band_rows, r, world) * line > stride_bytes) return MRT_ERR_INVALID;
+    for (uint32_t y = 0; y < yres; ++y) {
+        const uint32_t band = y / band_rows, within = y % band_rows;
+        const uint32_t rank = band % world, local_band = band / world;
+        const size_t lr = (size_t)local_band * band_rows + within;
+        std::memcpy(image_out + (size_t)y * line, gathered + (size_t)rank * stride_bytes + lr * line, line);
+    }
+    return MRT_OK;
+}
+
+}  // extern "C"

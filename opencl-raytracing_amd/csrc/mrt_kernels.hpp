@@ -1,0 +1,50 @@
+// mrt_kernels.hpp -- parameter block shared by host code and the render kernel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrt {
+
+// Geometry of the pixel->lane mapping.  One 64-lane wavefront owns a 32x32
+// pixel tile: lanes form an 8x8 grid and each lane owns a 4x4 block, so every
+// record a wave fetches from LDS is reused for 16 pixels per lane and each
+// lane's row segment is one aligned 16-byte RGBA8 store.
+constexpr int kLanePx = 4;                 // pixels per lane, per axis
+constexpr int kWaveTile = 8 * kLanePx;     // 32
+constexpr int kBlockWavesX = 2, kBlockWavesY = 2;
+constexpr int kBlockThreads = 64 * kBlockWavesX * kBlockWavesY;   // 256
+constexpr int kBlockTileX = kWaveTile * kBlockWavesX;             // 64
+constexpr int kBlockTileY = kWaveTile * kBlockWavesY;             // 64
+
+// Triangles per LDS chunk and per any-lane-passes check.
+constexpr int kChunkTris = 256;
+constexpr int kGroupTris = 4;
+
+struct RenderParams {
+    float eye[3], u[3], v[3], w[3];
+    float left, right, top, bottom;
+    float xres_f, yres_f;
+    float focal;
+    float ka, kd, ks;
+    float amb[3];
+    float bg[3];
+    int32_t shader;
+    uint32_t flags;
+    uint32_t xres, yres;            // whole image
+    uint32_t band_rows, rank, world;  // interleaved row-band partition
+    uint32_t local_rows;            // rows this launch renders (packed)
+    uint32_t n_sph, n_tri, n_tri_padded, n_lights;
+    const float4* tri_filter;       // 3 x float4 per triangle, padded to kChunkTris
+    const float4* tri_exact;        // 3 x float4 per triangle: (a, mat) (b, -) (c, -)
+    const float4* sph;              // (cx, cy, cz, r)
+    const uint32_t* sph_mat;
+    const float4* mats;             // (r, g, b, shininess)
+    const float4* lights;           // 2 x float4 per light: (pos, -) (colour, -)
+    uint32_t* out;                  // RGBA8, local_rows x xres
+    int32_t* ids;                   // optional, local_rows x xres
+    float* tvals;                   // optional
+    unsigned long long* exact_counter;  // optional
+};
+
+}  // namespace mrt

@@ -1,0 +1,237 @@
+"""Host-side logic that needs no GPU: the C ABI's symbol table, the scene
+loader (schema, validation order and messages of rayson.hpp:380-638), the band
+partition helpers, the PNG writer and the CLI contract (mrraytracer.cpp:23-148)."""
+import ctypes
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import SCENES, ALL_SCENES, ROOT
+import scene_py
+
+CLI = ROOT / "opencl-raytracing_amd" / "mrraytracer"
+
+
+def test_library_exports_every_declared_symbol(mrt):
+    L = mrt.lib()
+    for name in mrt.EXPORTED_SYMBOLS:
+        assert hasattr(L, name), name
+    # the header and the list agree
+    import re
+    header = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "mrt.h").read_text(), flags=re.S)
+    declared = set(re.findall(r"\b(mrt_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(mrt.EXPORTED_SYMBOLS)
+    assert L.mrt_abi_version() == 1
+
+
+def test_struct_sizes_match_reference_layout(mrt):
+    # CLStructs.hpp:8-128 (packed, cl_float3 = 16 bytes)
+    sizes = {"float3": 16, "float2": 8, "rgb": 16, "light": 48, "cam": 64, "vp": 32, "ray": 32, "phong": 32,
+             "object": 144, "intersect": 80}
+    for k, v in sizes.items():
+        assert mrt.CL_DTYPES[k].itemsize == v, k
+    x = mrt.CL_DTYPES["intersect"]
+    assert x.fields["t_"][1] == 33 and x.fields["shininess"][1] == 60 and x.fields["color"][1] == 64
+    o = mrt.CL_DTYPES["object"]
+    assert o.fields["center"][1] == 100 and o.fields["is_triangle"][1] == 128
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_loader_matches_independent_reader(mrt, name):
+    ls = mrt.LoadedScene(path=SCENES / f"{name}.json")
+    a = ls.copy()
+    b = scene_py.load_scene(SCENES / f"{name}.json")
+    sa, sb = a.struct, b.struct
+    for f in ("eye", "u", "v", "w", "ambient", "background"):
+        assert list(getattr(sa, f)) == list(getattr(sb, f)), f
+    for f in ("xres", "yres", "left", "right", "top", "bottom", "projection", "focal", "shader", "ka", "kd",
+              "ks", "n_spheres", "n_tris", "n_materials", "n_lights"):
+        assert getattr(sa, f) == getattr(sb, f), f
+    for f in ("sph", "tri", "mat", "light", "sph_mat", "tri_mat"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    ls.close()
+
+
+def test_teatime_object_counts(mrt):
+    ls = mrt.LoadedScene(path=SCENES / "teatime.json")
+    assert ls.struct.n_spheres == 2 and ls.struct.n_tris == 4032 and ls.struct.n_lights == 2
+    assert ls.struct.n_materials == 3
+    assert ls.info.light_intensity[0] == 1.1
+
+
+BASE = {
+    "camera_eye": [0, 0, 0], "camera_up": [0, -1, 0], "camera_view": [0, 0, 1],
+    "x_resolution": 40, "y_resolution": 30,
+    "viewport_left": -1.0, "viewport_top": 1.0, "viewport_right": 1.0, "viewport_bottom": -1.0,
+    "background": [0.7, 0.7, 0.9], "ortho_projection": True, "flat_shader": True,
+    "materials": [{"name": "red", "color": [1.0, 0.0, 0.0], "shininess": 4.0}],
+    "spheres": [{"material": "red", "center": [0, 0, 2], "radius": 0.5}],
+}
+
+
+def mutate(**kw):
+    d = json.loads(json.dumps(BASE))
+    for k, v in kw.items():
+        if v is None:
+            d.pop(k, None)
+        else:
+            d[k] = v
+    return json.dumps(d)
+
+
+def load_err(mrt, text):
+    with pytest.raises(mrt.MrtError) as e:
+        mrt.LoadedScene(text=text)
+    return e.value.message
+
+
+def test_loader_accepts_base(mrt):
+    ls = mrt.LoadedScene(text=mutate())
+    assert ls.struct.xres == 40 and ls.struct.yres == 30 and ls.struct.n_spheres == 1
+
+
+# (mutation, message) -- messages are the reference loader's, rayson.hpp:380-638
+CASES = [
+    (dict(camera_eye=None), 'missing key "camera_eye"'),
+    (dict(camera_up=5), "expected camera_up to be an array"),
+    (dict(camera_view=[0, 0]), None),   # count in the message is the enclosing object's size
+    (dict(camera_eye=[0, "a", 0]), "vector3 must contain numbers"),
+    (dict(x_resolution=40.0), 'key "x_resolution" must be an integer'),
+    (dict(y_resolution=0), 'key "y_resolution" must be positive'),
+    (dict(y_resolution=-3), 'key "y_resolution" must be positive'),
+    (dict(viewport_left=-1), 'key "viewport_left" must be a float'),
+    (dict(viewport_left=1.0), 'key "viewport_left" must be negative'),
+    (dict(viewport_top=-1.0), 'key "viewport_top" must be positive'),
+    (dict(viewport_right=0.0), 'key "viewport_right" must be positive'),
+    (dict(viewport_bottom=0.5), 'key "viewport_bottom" must be negative'),
+    (dict(persp_focal_length=1.0), "cannot have both ortho_projection and persp_focal_length"),
+    (dict(ortho_projection=None), "must have ortho_projection or persp_focal_length"),
+    (dict(ortho_projection=False), "ortho_projection, if present, must be true"),
+    (dict(ortho_projection=1), 'key "ortho_projection" must be a bool'),
+    (dict(ortho_projection=None, persp_focal_length=-2.0), 'key "persp_focal_length" must be positive'),
+    (dict(ortho_projection=None, persp_focal_length=2), 'key "persp_focal_length" must be a float'),
+    (dict(flat_shader=False), "flat_shader, if present, must be true"),
+    (dict(flat_shader=None), "must have flat_shader or phong_shader"),
+    (dict(flat_shader=None, phong_shader={"ambient_coeff": 0.1, "diffuse_coeff": 0.5}),
+     'missing key "specular_coeff"'),
+    (dict(flat_shader=None, phong_shader={"ambient_coeff": -0.1, "diffuse_coeff": 0.5, "specular_coeff": 0.1,
+                                          "ambient_color": [1, 1, 1]}), 'key "ambient_coeff" must be non-negative'),
+    (dict(background=[0.7, 1.5, 0.9]), "color has g component outside the range [0, 1]"),
+    (dict(background=[-0.7, 0.5, 0.9]), "color has r component outside the range [0, 1]"),
+    (dict(background=[0.7, 0.5, 9]), "color has b component outside the range [0, 1]"),
+    (dict(point_lights={"a": 1}), "expected point_lights to be an array"),
+    (dict(point_lights=[{"location": [0, 0, 0], "color": [1, 1, 1], "intensity": 0.0}]),
+     'key "intensity" must be positive'),
+    (dict(materials=None), "no materials list"),
+    (dict(materials=[{"name": "red", "color": [1, 0, 0], "shininess": 4.0},
+                     {"name": "red", "color": [0, 1, 0], "shininess": 4.0}]), 'duplicate material name "red"'),
+    (dict(materials=[{"name": 3, "color": [1, 0, 0], "shininess": 4.0}]), 'key "name" must be a string'),
+    (dict(materials=[{"name": "red", "color": [1, 0, 0], "shininess": 4}]), 'key "shininess" must be a float'),
+    (dict(spheres=[{"material": "blue", "center": [0, 0, 2], "radius": 0.5}]),
+     'sphere references undefined material "blue"'),
+    (dict(spheres=[{"material": "red", "center": [0, 0, 2], "radius": -0.5}]), 'key "radius" must be positive'),
+    (dict(triangles=[{"material": "red", "a": [0, 0, 1], "b": [0, 0, 1], "c": [1, 0, 1]}]),
+     "triangle is degenerate due to duplicated vertices"),
+    (dict(triangles=[{"material": "nope", "a": [0, 0, 1], "b": [0, 1, 1], "c": [1, 0, 1]}]),
+     'triangle references undefined material "nope"'),
+]
+
+
+@pytest.mark.parametrize("mutation,message", CASES, ids=[str(i) for i in range(len(CASES))])
+def test_loader_error_messages(mrt, mutation, message):
+    msg = load_err(mrt, mutate(**mutation))
+    if message is None:
+        n_keys = len(json.loads(mutate(**mutation)))
+        message = f"expected array camera_view to have 3 elements, but found {n_keys} elements"
+    assert msg == message
+
+
+def test_loader_misc(mrt):
+    assert load_err(mrt, "[1, 2]") == "rayson must be comprised of one JSON object"
+    assert load_err(mrt, '{"a": }') == 'JSON parse error reading "<memory>"'
+    with pytest.raises(mrt.MrtError) as e:
+        mrt.LoadedScene(path="/nonexistent/scene.json")
+    assert e.value.message == 'could not open "/nonexistent/scene.json"'
+    # flat_shader wins when both shaders are present; integers are fine inside vectors;
+    # unknown keys are ignored; later duplicates of a key win.
+    ls = mrt.LoadedScene(text=mutate(phong_shader={"x": 1}, some_unknown_key=[1, 2, 3]))
+    assert ls.struct.shader == mrt.SHADER_FLAT
+    text = mutate()[:-1] + ', "x_resolution": 77}'
+    assert mrt.LoadedScene(text=text).struct.xres == 77
+    # trailing text after the first JSON value is not an error (stream extraction)
+    assert mrt.LoadedScene(text=mutate() + "\n\ntrailing").struct.xres == 40
+
+
+def test_band_partition_helpers(mrt):
+    rng = np.random.default_rng(1)
+    for yres, b, world in [(2160, 64, 8), (400, 64, 3), (17, 5, 4), (64, 64, 2), (1, 8, 8), (100, 7, 1)]:
+        rows = [mrt.band_rows(yres, b, r, world) for r in range(world)]
+        assert sum(rows) == yres
+        xres = 5
+        img = rng.integers(0, 255, (yres, xres, 4), dtype=np.uint8)
+        stride = max(rows) * xres * 4
+        gathered = np.zeros((world, stride), np.uint8)
+        for r in range(world):
+            mine = [y for y in range(yres) if (y // b) % world == r]
+            assert len(mine) == rows[r]
+            gathered[r, :len(mine) * xres * 4] = img[mine].reshape(-1)
+        back = mrt.bands_to_image(gathered, stride, xres, yres, b, world)
+        assert np.array_equal(back, img)
+    assert mrt.band_rows(100, 0, 0, 1) == 0 and mrt.band_rows(100, 8, 3, 2) == 0
+
+
+def test_png_writer_roundtrip(mrt, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for (h, w) in [(1, 1), (7, 13), (400, 400), (1500, 1100)]:   # the last spans several deflate stripes
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        img[h // 2:] = 7    # compressible half
+        p = tmp_path / f"t_{h}_{w}.png"
+        mrt.write_png_rgb(p, img)
+        with Image.open(p) as im:
+            assert im.mode == "RGB" and im.size == (w, h)      # 8-bit RGB, no alpha (gfxpng.hpp:67-79)
+            back = np.asarray(im)
+        assert np.array_equal(back, img[..., :3])
+
+
+def test_cli_usage_and_errors(tmp_path):
+    r = subprocess.run([str(CLI)], capture_output=True, text=True)
+    assert r.returncode == 255     # main returns -1 (mrraytracer.cpp:24-27)
+    assert r.stdout == "mrraytracer usage:\n\n./mrraytracer <INPUT-JSON-SCENE-PATH> <OUTPUT-PNG-PATH>\n\n"
+    bad = tmp_path / "bad.json"
+    bad.write_text(mutate(materials=None))
+    r = subprocess.run([str(CLI), str(bad), str(tmp_path / "o.png")], capture_output=True, text=True)
+    assert r.returncode == 1
+    assert r.stderr == f'error loading scene "{bad}": no materials list\n'
+    assert r.stdout == ""
+
+
+def test_cli_scene_summary_format(tmp_path):
+    # Runs up to the render step; without a GPU that step must fail loudly (no CPU fallback).
+    r = subprocess.run([str(CLI), str(SCENES / "scene_2spheres_persp_phong.json"), str(tmp_path / "o.png")],
+                       capture_output=True, text=True)
+    want = (
+        "scene has:\n"
+        "    camera eye=<0, 0, 0> u=<1, 0, -0> v=<0, -1, 0> w=<-0, -0, -1>\n"
+        "    viewport x_res=400 y_res=400 left=-1 top=1 right=1 bottom=-1\n"
+        "    projection is PERSPECTIVE with focal_length=1\n"
+        "    shader is BLINN-PHONG with\n"
+        "         ambient_coefficient=0.05\n"
+        "         ambient_color=<1.000000, 1.000000, 1.000000>\n"
+        "         diffuse_coefficient=0.5\n"
+        "         specular_coefficient=0.25\n"
+        "    background=<0.700000, 0.700000, 0.900000>\n"
+        "    count of lights=2\n"
+        "        location=<-2, 2, -1> color=<1.000000, 1.000000, 1.000000> intensity=1.1\n"
+        "        location=<1, 0, -1> color=<1.000000, 1.000000, 1.000000> intensity=0.25\n"
+        "    count of objects=2\n"
+        "raytracing...")
+    assert r.stdout.startswith(want)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode == 1 and "render failed" in r.stderr
+    else:
+        assert r.returncode == 0 and r.stdout.endswith("done\n\n")

@@ -1,0 +1,160 @@
+"""Pins the CPU oracle with analytic known-answer values.
+
+The reference has no tests or golden images for this path; every number below
+follows from the shipped scene files and the formulas of kernel.cl alone
+(pixel centre offset +1/+0.5, kernel.cl:126-127 with gfxraytrace.hpp:850-852;
+truncating byte conversion, gfximage.hpp:46-51).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import SCENES, GOLDEN, ALL_SCENES, SMALL_SCENES
+import scene_py
+
+
+def load(name, **kw):
+    return scene_py.load_scene(SCENES / f"{name}.json", **kw)
+
+
+def test_byte_conversion_truncates(oracle):
+    # 0.2 -> 51, 0.9 -> 229, 0.4 -> 102, 0.7 -> 178, 1.0 -> 255, 0 -> 0
+    for x, b in [(0.2, 51), (0.9, 229), (0.4, 102), (0.7, 178), (1.0, 255), (0.0, 0), (0.999, 254)]:
+        assert oracle.to_byte(np.float32(x)) == b
+    assert oracle.to_byte(float("nan")) == 0
+
+
+def test_camera_basis(oracle):
+    # eye 0, up (0,-1,0), view (0,0,1)  =>  u=(1,0,0) v=(0,-1,0) w=(0,0,-1)  (gfxraytrace.hpp:881-889)
+    u, v, w = oracle.camera_basis([0, 0, 1], [0, -1, 0])
+    assert np.allclose(u, [1, 0, 0]) and np.allclose(v, [0, -1, 0]) and np.allclose(w, [0, 0, -1])
+    u2, v2, w2 = scene_py.camera_basis([0.0, 0.0, 1.0], [0.0, -1.0, 0.0])
+    assert np.array_equal(u, u2) and np.array_equal(v, v2) and np.array_equal(w, w2)
+    # teatime: view (0,-1,0), up (0,0,-1)
+    u, v, w = oracle.camera_basis([0, -1, 0], [0, 0, -1])
+    assert np.allclose(w, [0, 1, 0]) and np.allclose(u, [1, 0, 0]) and np.allclose(v, [0, 0, -1])
+
+
+def test_uv_kat(oracle, mrt):
+    # uv = -1 + 0.005*(x + 1.5): pixel (0,0) -> -0.9925, (399,399) -> 1.0025, (99,200) -> (-0.4975, 0.0075)
+    pos = np.zeros(3, mrt.CL_DTYPES["float3"])
+    pos["s"][:, :2] = [[1, 1], [400, 400], [100, 201]]   # host grid is (x+1, y+1)
+    vp = np.zeros(1, mrt.CL_DTYPES["vp"])
+    vp["x_resolution"] = vp["y_resolution"] = 400
+    vp["left"], vp["right"], vp["top"], vp["bottom"] = -1, 1, 1, -1
+    uv = oracle.stage_uv(pos, vp)["s"]
+    want = np.array([[-0.9925, -0.9925], [1.0025, 1.0025], [-0.4975, 0.0075]], np.float64).astype(np.float32)
+    assert np.array_equal(uv, want)
+
+
+def test_flat_colours_and_hit_counts(oracle):
+    r = oracle.render(load("scene_gtri_ortho_flat"))
+    hit = r["ids"] >= 0
+    # triangle area 0.18 in a 2x2 viewport at 400x400 -> 0.18 / 0.005^2 = 7200 pixels
+    assert abs(int(hit.sum()) - 7200) <= 72
+    assert (r["rgba"][hit] == [51, 229, 51, 255]).all()
+    assert (r["rgba"][~hit] == [102, 102, 102, 255]).all()
+    assert np.allclose(r["t"][hit], 2.0)          # every orthographic hit is at t = 2 exactly
+
+    r = oracle.render(load("scene_gtri_persp_flat"))
+    assert abs(int((r["ids"] >= 0).sum()) - 1800) <= 36    # projected area / 4
+
+    r = oracle.render(load("scene_2spheres_ortho_flat"))
+    hit = r["ids"] >= 0
+    # two half discs of radius 100 px -> pi * 100^2
+    assert abs(int(hit.sum()) - math.pi * 1e4) <= 0.01 * math.pi * 1e4
+    assert (r["rgba"][r["ids"] == 0] == [255, 0, 0, 255]).all()
+    assert (r["rgba"][r["ids"] == 1] == [0, 0, 255, 255]).all()
+    assert (r["rgba"][~hit] == [178, 178, 229, 255]).all()
+    assert r["ids"][200, 99] == -1                 # |-0.4975 + 1| = 0.5025 > r
+
+
+def test_phong_kat(oracle):
+    # scene_gtri_ortho_phong pixel (199,199): hand-computed (163, 255, 163)
+    r = oracle.render(load("scene_gtri_ortho_phong"), want_rgbf=True)
+    assert tuple(r["rgba"][199, 199][:3]) == (163, 255, 163)
+    assert abs(r["rgbf"][199, 199][0] - 0.6413) < 5e-4 and r["rgbf"][199, 199][1] == 1.0
+    # scene_2spheres_persp_*: pixel (99,200): d = (-0.4975, -0.0075, 1), t = 1.55447 on sphere 0
+    r = oracle.render(load("scene_2spheres_persp_phong"), want_rgbf=True)
+    assert r["ids"][200, 99] == 0
+    assert abs(r["t"][200, 99] - 1.55447) < 1e-5
+    a = 0.4975 ** 2 + 0.0075 ** 2 + 1
+    b = (-0.4975) * 1 + 1 * (-2)                   # d . (o - c), o = 0, c = (-1, 0, 2)
+    c = 1 + 4 - 0.25
+    t = (-b - math.sqrt(b * b - a * c)) / a
+    assert abs(r["t"][200, 99] - t) < 1e-6
+
+
+def test_sphere_near_root_only(oracle, mrt):
+    # camera inside a sphere: the near root is negative, so it is a miss (kernel.cl:262-281)
+    sc = mrt.Scene(eye=[0, 0, 0], u=[1, 0, 0], v=[0, -1, 0], w=[0, 0, -1], xres=8, yres=8, left=-1, right=1,
+                   top=1, bottom=-1, projection=mrt.PROJ_PERSP, focal=1.0, background=(0.1, 0.2, 0.3),
+                   sph=[[0], [0], [0], [5.0]], sph_mat=[0], mat=[[1], [1], [1], [4]])
+    r = oracle.render(sc)
+    assert (r["ids"] == -1).all()
+
+
+def test_ortho_origin_drops_eye(oracle, mrt):
+    # kernel.cl:133-136: the orthographic origin ignores the eye.  A triangle
+    # at z=2 is hit at t=2 wherever the eye is.
+    kw = dict(u=[1, 0, 0], v=[0, -1, 0], w=[0, 0, -1], xres=16, yres=16, left=-1, right=1, top=1, bottom=-1,
+              projection=mrt.PROJ_ORTHO, background=(0, 0, 0),
+              tri=[[-5], [5], [2], [5], [5], [2], [0], [-5], [2]], tri_mat=[0], mat=[[1], [1], [1], [4]])
+    r0 = oracle.render(mrt.Scene(eye=[0, 0, 0], **kw))
+    r1 = oracle.render(mrt.Scene(eye=[3, 4, -50], **kw))
+    assert (r0["ids"] == 0).any()
+    assert np.array_equal(r0["t"], r1["t"]) and np.array_equal(r0["ids"], r1["ids"])
+
+
+def test_tie_goes_to_earlier_object(oracle, mrt):
+    # two identical triangles: strict t < best keeps the first (kernel.cl:326)
+    tri = [[-5, -5], [5, 5], [2, 2], [5, 5], [5, 5], [2, 2], [0, 0], [-5, -5], [2, 2]]
+    sc = mrt.Scene(eye=[0, 0, 0], u=[1, 0, 0], v=[0, -1, 0], w=[0, 0, -1], xres=8, yres=8, left=-1, right=1,
+                   top=1, bottom=-1, projection=mrt.PROJ_ORTHO, background=(0, 0, 0), tri=tri, tri_mat=[0, 1],
+                   mat=[[1, 0], [0, 1], [0, 0], [4, 4]])
+    r = oracle.render(sc)
+    assert set(np.unique(r["ids"])) <= {-1, 0} and (r["ids"] == 0).any()
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_golden_fixtures_match_oracle(oracle, name):
+    g = np.load(GOLDEN / f"{name}.npz")
+    r = oracle.render(load(name), threads=4)
+    assert np.array_equal(r["rgba"], g["rgba"])
+    assert np.array_equal(r["ids"], g["ids"])
+    assert np.array_equal(r["t"], g["t"])
+
+
+@pytest.mark.parametrize("name", SMALL_SCENES)
+def test_oracle_agrees_with_float64_model(oracle, name):
+    import specmodel
+    from parity import check
+    sc = load(name)
+    r = oracle.render(sc)
+    s = specmodel.render(sc)
+    check(s["rgba"], r["rgba"], r["ids"])
+    mism = r["ids"] != s["ids"]
+    assert mism.sum() <= 0.001 * mism.size
+
+
+def test_oracle_agrees_with_float64_model_teatime_crop(oracle):
+    # the full 400x400 teatime comparison takes minutes in numpy; a 200x200
+    # render of the same view keeps the mesh, both spheres and all 4032 triangles.
+    import specmodel
+    from parity import check
+    sc = load("teatime", xres=200, yres=200)
+    r = oracle.render(sc, threads=4)
+    s = specmodel.render(sc, chunk=32)
+    check(s["rgba"], r["rgba"], r["ids"])
+    assert (r["ids"] != s["ids"]).sum() <= 0.001 * r["ids"].size
+
+
+def test_threads_and_row_ranges_are_invariant(oracle):
+    sc = load("scene_2spheres_persp_phong")
+    full = oracle.render(sc, threads=1)
+    par = oracle.render(sc, threads=7)
+    assert np.array_equal(full["rgba"], par["rgba"])
+    part = oracle.render(sc, rows=(100, 233), threads=3)
+    assert np.array_equal(part["rgba"][100:233], full["rgba"][100:233])
+    assert (part["rgba"][:100] == 0).all()
