@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric "Mrays/sec + ray-prim tests/sec vs FP32 peak,
+teatime 4K"): the teatime mesh (2 spheres + 4032 triangles, 2 lights,
+perspective, Blinn-Phong) at 3840x2160, every ray tested against every
+primitive.  One step = one frame: ray generation, closest hit, shading, RGBA8
+bytes in HBM.  With N > 1 ranks (one process per GPU, launched by
+torch.distributed.run) the frame grows to 3840 x (2160*N) with the viewport's
+top/bottom scaled by N, so every rank still renders 2160 rows' worth of
+interleaved 64-row bands ("weak" scaling: fixed work per GPU), and the step
+includes gathering all bands to rank 0 over RCCL.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel
+(trace_kernel): algorithmic FLOPs per launch = rays * (4032 * 45 + 2 * 20)
+(45 FLOPs per ray-triangle test, 20 per ray-sphere test, brute force, no
+culling credit) over the kernel's mean duration measured with HIP events on
+the launch stream, against the 157.3 TFLOP/s FP32 vector peak.  `cpu_baseline`
+times the CPU oracle (oracle/mrt_oracle.c, a restatement of the reference
+arithmetic -- the reference has no CPU path of its own and may not be run) on
+a bounded row sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
+
+FLOPS_PER_TRI_TEST = 45.0
+FLOPS_PER_SPH_TEST = 20.0
+FP32_PEAK_TFLOPS = 157.3          # 256 CU x 128 lanes x 2 FLOP x 2.4 GHz
+BAND_ROWS = 64
+XRES, YRES = 3840, 2160
+
+
+def build_scene(mrt, mkscene, world):
+    """teatime at 3840 x (2160*world); world == 1 is the BASELINE 4K frame."""
+    text = mkscene.teatime(XRES, YRES)
+    ls = mrt.LoadedScene(text=text)          # the product's own loader
+    sc = ls.copy()
+    if world > 1:
+        sc = sc.with_resolution(XRES, YRES * world, top=float(world), bottom=-float(world))
+    return sc
+
+
+def cpu_baseline(sc, seconds_target=12.0):
+    """Oracle on the host cores, bounded sample: rows from the middle of the frame."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle_py
+    threads = min(16, os.cpu_count() or 1)
+    st = sc.struct
+    n_prims = st.n_spheres + st.n_tris
+    # calibrate on 4 rows, then size the sample for ~seconds_target
+    mid = st.yres // 2
+    t0 = time.perf_counter()
+    oracle_py.render(sc, rows=(mid, mid + threads), threads=threads)
+    dt = time.perf_counter() - t0
+    rows = int(max(threads, min(st.yres // 2, threads * seconds_target / max(dt, 1e-3))))
+    rows -= rows % threads
+    r0 = max(0, mid - rows // 2)
+    t0 = time.perf_counter()
+    oracle_py.render(sc, rows=(r0, r0 + rows), threads=threads)
+    dt = time.perf_counter() - t0
+    rays = rows * st.xres
+    return {
+        "value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"rows {r0}..{r0 + rows} of the {st.xres}x{st.yres} frame ({rays} rays x {n_prims} "
+                  f"primitives, {dt:.2f} s, {threads} threads)",
+        "prim_tests_per_s": rays * n_prims / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch          # before the HIP library: one HIP runtime per process
+    import torch.distributed as dist
+    import mrt_pkg
+    import mkscene
+    mrt = mrt_pkg.load()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    sc = build_scene(mrt, mkscene, world)
+    st = sc.struct
+    ctx = mrt.Context(device=local_rank)
+    ctx.set_scene(sc)
+    rows = mrt.band_rows(st.yres, BAND_ROWS, rank, world)
+    row_bytes = st.xres * 4
+    max_rows = max(mrt.band_rows(st.yres, BAND_ROWS, r, world) for r in range(world))
+    local = torch.empty(max_rows * row_bytes, dtype=torch.uint8, device=dev)
+    gathered = ([torch.empty(max_rows * row_bytes, dtype=torch.uint8, device=dev) for _ in range(world)]
+                if (world > 1 and rank == 0) else None)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        ctx.render_bands_device(BAND_ROWS, rank, world, local.data_ptr(), local.numel(),
+                                stream=stream.cuda_stream)
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # Kernel-only duration of the dominant kernel: HIP events on the launch stream.
+    trace_ms = []
+    shade_ms = []
+    for _ in range(max(10, min(args.steps, 50))):
+        s = ctx.render_bands_device(BAND_ROWS, rank, world, local.data_ptr(), local.numel(),
+                                    stream=stream.cuda_stream, timed=True)
+        trace_ms.append(s.trace_ms)
+        shade_ms.append(s.shade_ms)
+    trace_avg = sum(trace_ms) / len(trace_ms)
+    shade_avg = sum(shade_ms) / len(shade_ms)
+
+    if rank == 0:
+        total_rays = st.xres * st.yres                      # all ranks together, per step
+        n_prims = st.n_spheres + st.n_tris
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_rays * args.steps / elapsed * 1e-6
+        rays_rank = rows * st.xres
+        flops_launch = rays_rank * (st.n_tris * FLOPS_PER_TRI_TEST + st.n_spheres * FLOPS_PER_SPH_TEST)
+        achieved = flops_launch / (trace_avg * 1e-3) * 1e-12
+        out = {
+            "metric": "Mrays/s, teatime 3840x2160 Blinn-Phong, brute-force closest hit over 4034 primitives",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "teatime_4k" if world == 1 else f"teatime_3840x{st.yres}_bands{BAND_ROWS}",
+                       "xres": st.xres, "yres": st.yres, "rays_per_step": total_rays,
+                       "primitives": n_prims, "band_rows": BAND_ROWS,
+                       "gather": "rccl gather to rank 0" if world > 1 else "none",
+                       "output": "RGBA8 resident in HBM (no D2H in the timed region)"},
+            "prim_tests_per_s": value * 1e6 * n_prims,
+            "roofline": {
+                "bound": "valu", "kernel": "trace_kernel", "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                "kernel_ms": trace_avg, "shade_kernel_ms": shade_avg,
+                "flops_per_launch": flops_launch,
+                "note": "algorithmic FLOPs: 45 per ray-triangle test, 20 per ray-sphere test, every ray x "
+                        "every primitive; the kernel rejects most pairs with a cheaper conservative test, so "
+                        "executed FLOPs are lower (see DESIGN.md)",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sc)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -125,6 +126,15 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own HIP runtime (same SONAME as the system
+    # one).  Two HIP runtimes in one process cannot both open the GPU, so when
+    # torch is installed it is imported first and this library binds to the
+    # runtime torch has already loaded.
+    if "torch" not in sys.modules and os.environ.get("MRT_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     path = lib_path()
     if not path.exists():
         raise OSError(f"{path} not found: build it with `make -C {PKG_DIR}` (hipcc, gfx950)")

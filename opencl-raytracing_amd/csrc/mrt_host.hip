@@ -39,6 +39,7 @@ struct mrt_ctx {
     double upload_ms = 0.0;
 
     // scene buffers
+    void* d_sph_filter = nullptr;
     void* d_tri_filter = nullptr;
     void* d_tri_exact = nullptr;
     void* d_sph = nullptr;
@@ -114,12 +115,23 @@ inline double permabs(D3 a, D3 b, D3 c) {
 
 const float kAlways = 1e30f;
 
-void push_const_record(std::vector<float4>& rec, float c) {
-    for (int k = 0; k < 3; ++k) rec.push_back(make_float4(0.f, 0.f, c, 0.f));
+// One edge function A*x + B*y + C of a triangle record.
+struct Edge { float A, B, C; };
+
+// Triangle record as the kernel reads it from LDS: two 16-byte loads and one
+// 4-byte load, (A0,B0,C0,A1) (B1,C1,A2,B2) (C2,-,-,-).
+void push_record(std::vector<float4>& rec, const Edge e[3]) {
+    rec.push_back(make_float4(e[0].A, e[0].B, e[0].C, e[1].A));
+    rec.push_back(make_float4(e[1].B, e[1].C, e[2].A, e[2].B));
+    rec.push_back(make_float4(e[2].C, 0.f, 0.f, 0.f));
 }
 
-void push_edge(std::vector<float4>& rec, double a, double b, double c, double margin, double xres,
-               double yres) {
+void push_const_record(std::vector<float4>& rec, float c) {
+    const Edge e[3] = {{0.f, 0.f, c}, {0.f, 0.f, c}, {0.f, 0.f, c}};
+    push_record(rec, e);
+}
+
+Edge make_edge(double a, double b, double c, double margin, double xres, double yres) {
     double g = std::hypot(a, b);
     double A, B, C;
     if (g > 0.0 && std::isfinite(g)) {
@@ -134,7 +146,7 @@ void push_edge(std::vector<float4>& rec, double a, double b, double c, double ma
     // multiply-adds (plus up to three additions along a row) in the kernel.
     C += 16.0 * (1.0 / 16777216.0) * (std::fabs(A) * xres + std::fabs(B) * yres + std::fabs(C));
     if (!(std::fabs(C) < 1e30)) C = (C > 0 || C != C) ? 1e30 : -1e30;
-    rec.push_back(make_float4((float)A, (float)B, (float)C, 0.f));
+    return Edge{(float)A, (float)B, (float)C};
 }
 
 void build_filter_records(const mrt_scene& s, std::vector<float4>& rec) {
@@ -179,9 +191,11 @@ void build_filter_records(const mrt_scene& s, std::vector<float4>& rec) {
             const double dD = K * permabs(absv(s1), absv(s2), vabs);
             const double maxD = dot(absv(n), vabs);
             const double m2 = dU + dV + 2 * dD + K * maxD;
-            push_edge(rec, sg * dot(P0, Vx), sg * dot(P0, Vy), sg * dot(P0, V0), dU, xres, yres);
-            push_edge(rec, sg * dot(P1, Vx), sg * dot(P1, Vy), sg * dot(P1, V0), dV, xres, yres);
-            push_edge(rec, sg * dot(P2, Vx), sg * dot(P2, Vy), sg * dot(P2, V0), m2, xres, yres);
+            const Edge e[3] = {
+                make_edge(sg * dot(P0, Vx), sg * dot(P0, Vy), sg * dot(P0, V0), dU, xres, yres),
+                make_edge(sg * dot(P1, Vx), sg * dot(P1, Vy), sg * dot(P1, V0), dV, xres, yres),
+                make_edge(sg * dot(P2, Vx), sg * dot(P2, Vy), sg * dot(P2, V0), m2, xres, yres)};
+            push_record(rec, e);
         } else {
             const D3 d = dortho;
             const double Det = dot(d, n);
@@ -196,13 +210,98 @@ void build_filter_records(const mrt_scene& s, std::vector<float4>& rec) {
             const double m2 = dU + dV + 2 * dD + K * std::fabs(Det);
             const double u0 = dot(a0, Q0), ux = -dot(Vx, Q0), uy = -dot(Vy, Q0);
             const double v0 = dot(a0, Q1), vx = -dot(Vx, Q1), vy = -dot(Vy, Q1);
-            push_edge(rec, sg * ux, sg * uy, sg * u0, dU, xres, yres);
-            push_edge(rec, sg * vx, sg * vy, sg * v0, dV, xres, yres);
-            push_edge(rec, sg * (-ux - vx), sg * (-uy - vy), sg * (Det - u0 - v0), m2, xres, yres);
+            const Edge e[3] = {
+                make_edge(sg * ux, sg * uy, sg * u0, dU, xres, yres),
+                make_edge(sg * vx, sg * vy, sg * v0, dV, xres, yres),
+                make_edge(sg * (-ux - vx), sg * (-uy - vy), sg * (Det - u0 - v0), m2, xres, yres)};
+            push_record(rec, e);
         }
     }
     // Pad to whole chunks with records no pixel passes.
     while ((rec.size() / 3) % mrt::kChunkTris != 0) push_const_record(rec, -kAlways);
+}
+
+// ---------------------------------------------------------------------------
+// Per-frame sphere prefilter records (sx, ox, sy, oy): a pixel (x, y) can only
+// hit the sphere if (x*sx + ox)^2 + (y*sy + oy)^2 <= 1.  The ellipse is the
+// one circumscribing the pixel-space bounding box of the sphere's outline
+// (tangent rays from the eye for the pinhole camera, centre +- r for the
+// orthographic one), grown by a margin that covers the cancellation error of
+// the FP32 discriminant b*b - a*c the exact path evaluates (kernel.cl:248-254).
+// A sphere whose outline is unbounded or cannot be bounded reliably (it
+// reaches the eye plane, or the camera basis is not orthonormal) gets a
+// record every pixel passes.
+// ---------------------------------------------------------------------------
+void build_sphere_records(const mrt_scene& s, std::vector<float4>& rec) {
+    const float4 always = make_float4(0.f, 0.f, 0.f, 0.f);   // 0 + 0 <= 1
+    const float4 never = make_float4(0.f, 2.f, 0.f, 0.f);    // 4 > 1
+    const double xres = s.xres, yres = s.yres;
+    const double ux1 = (double)(float)(s.right - s.left) / (double)(float)s.xres;
+    const double uy1 = (double)(float)(s.top - s.bottom) / (double)(float)s.yres;
+    const double ux0 = (double)s.left + 1.5 * ux1;
+    const double uy0 = (double)s.bottom + 1.5 * uy1;
+    const D3 eye{s.eye[0], s.eye[1], s.eye[2]}, cu{s.u[0], s.u[1], s.u[2]}, cv{s.v[0], s.v[1], s.v[2]},
+        cw{s.w[0], s.w[1], s.w[2]};
+    const bool persp = s.projection == MRT_PROJ_PERSP;
+    const double f = s.focal;
+    const double tol = 1e-4;
+    const bool orthonormal = std::fabs(dot(cu, cu) - 1) < tol && std::fabs(dot(cv, cv) - 1) < tol &&
+                             std::fabs(dot(cw, cw) - 1) < tol && std::fabs(dot(cu, cv)) < tol &&
+                             std::fabs(dot(cu, cw)) < tol && std::fabs(dot(cv, cw)) < tol;
+    const double mux = std::fmax(std::fabs(ux0), std::fabs(ux0 + ux1 * (xres - 1)));
+    const double muy = std::fmax(std::fabs(uy0), std::fabs(uy0 + uy1 * (yres - 1)));
+    const double K = 64.0 / 16777216.0;
+
+    rec.clear();
+    rec.reserve((size_t)s.n_spheres + mrt::kChunkFloat4);
+    for (uint32_t k = 0; k < s.n_spheres; ++k) {
+        const D3 c{s.sph[0][k], s.sph[1][k], s.sph[2][k]};
+        const double r = std::fabs((double)s.sph[3][k]);
+        float4 out = always;
+        if (orthonormal && r > 0 && std::isfinite(r) && ux1 > 0 && uy1 > 0) {
+            double lo_u, hi_u, lo_v, hi_v, margin;
+            bool ok = true;
+            if (persp) {
+                const D3 oc = c - eye;
+                const double X = dot(oc, cu), Y = dot(oc, cv), Z = -dot(oc, cw);
+                const double rr = r * 1.001;
+                ok = f > 0 && Z > rr * 1.001 + 1e-30;
+                if (ok) {
+                    const double den = Z * Z - rr * rr;
+                    const double sx = rr * std::sqrt(X * X + den), sy = rr * std::sqrt(Y * Y + den);
+                    lo_u = f * (X * Z - sx) / den; hi_u = f * (X * Z + sx) / den;
+                    lo_v = f * (Y * Z - sy) / den; hi_v = f * (Y * Z + sy) / den;
+                    const double dist = std::sqrt(dot(oc, oc));
+                    const double dmax2 = f * f + mux * mux + muy * muy;
+                    // error of b*b - a*c over its gradient at the outline, in pixels
+                    margin = 1.0 + K * dist * dmax2 / (r * std::fmin(ux1, uy1) * f);
+                }
+            } else {
+                const double U = dot(c, cu), V = dot(c, cv);
+                lo_u = U - r * 1.001; hi_u = U + r * 1.001;
+                lo_v = V - r * 1.001; hi_v = V + r * 1.001;
+                const double reach = std::sqrt(dot(c, c)) + mux + muy + r;
+                margin = 1.0 + K * reach * reach / (r * std::fmin(ux1, uy1));
+            }
+            if (ok && std::isfinite(margin) && margin < 1e6) {
+                const double px0 = (lo_u - ux0) / ux1, px1 = (hi_u - ux0) / ux1;
+                const double py0 = (lo_v - uy0) / uy1, py1 = (hi_v - uy0) / uy1;
+                const double xc = 0.5 * (px0 + px1), yc = 0.5 * (py0 + py1);
+                const double hx = 0.5 * std::fabs(px1 - px0), hy = 0.5 * std::fabs(py1 - py0);
+                const double ax = 1.41421357 * hx + margin, ay = 1.41421357 * hy + margin;
+                if (std::isfinite(xc) && std::isfinite(yc) && std::isfinite(ax) && std::isfinite(ay)) {
+                    // grow once more for the FP32 evaluation of the two squares in the kernel
+                    const double grow = 1.0 + 1e-5 * (1.0 + (std::fabs(xc) + xres) / ax + (std::fabs(yc) + yres) / ay);
+                    const double sxx = 1.0 / (ax * grow), syy = 1.0 / (ay * grow);
+                    out = make_float4((float)sxx, (float)(-xc * sxx), (float)syy, (float)(-yc * syy));
+                    if (!std::isfinite(out.x) || !std::isfinite(out.y) || !std::isfinite(out.z) || !std::isfinite(out.w))
+                        out = always;
+                }
+            }
+        }
+        rec.push_back(out);
+    }
+    while (rec.size() % mrt::kChunkFloat4 != 0) rec.push_back(never);
 }
 
 int check_scene(mrt_ctx* ctx, const mrt_scene* s) {
@@ -361,7 +460,7 @@ void mrt_destroy(mrt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    free_dev(ctx->d_tri_filter); free_dev(ctx->d_tri_exact); free_dev(ctx->d_sph);
+    free_dev(ctx->d_sph_filter); free_dev(ctx->d_tri_filter); free_dev(ctx->d_tri_exact); free_dev(ctx->d_sph);
     free_dev(ctx->d_sph_mat); free_dev(ctx->d_mats); free_dev(ctx->d_lights);
     if (ctx->d_t) (void)hipFree(ctx->d_t);
     if (ctx->d_id) (void)hipFree(ctx->d_id);
@@ -380,8 +479,9 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->have_scene = false;
 
-    std::vector<float4> filt;
+    std::vector<float4> filt, sfilt;
     build_filter_records(*s, filt);
+    build_sphere_records(*s, sfilt);
     std::vector<float4> exact((size_t)s->n_tris * 3);
     for (uint32_t k = 0; k < s->n_tris; ++k) {
         float mbits;
@@ -406,6 +506,7 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
         lights[2 * (size_t)k + 1] = make_float4(s->light[3][k], s->light[4][k], s->light[5][k], 0.f);
     }
 
+    if ((rc = upload(ctx, ctx->d_sph_filter, sfilt)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_tri_filter, filt)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_tri_exact, exact)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_sph, sph)) != MRT_OK) return rc;
@@ -434,6 +535,8 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     p.xres = s->xres; p.yres = s->yres;
     p.n_sph = s->n_spheres; p.n_tri = s->n_tris;
     p.n_tri_padded = (uint32_t)(filt.size() / 3);
+    p.n_sph_padded = (uint32_t)sfilt.size();
+    p.sph_filter = (const float4*)ctx->d_sph_filter;
     p.n_lights = s->n_lights;
     p.tri_filter = (const float4*)ctx->d_tri_filter;
     p.tri_exact = (const float4*)ctx->d_tri_exact;

@@ -37,25 +37,76 @@ __device__ __forceinline__ uint32_t image_row(const RenderParams& p, uint32_t lr
     return (band * p.world + p.rank) * p.band_rows + within;
 }
 
+// The exact primary ray of a pixel from its two uv components.
 template <int PROJ>
-struct RaySetup {
-    // Column and row partial sums of the ray, associated exactly as the
-    // reference adds them: persp d = ((-w*f) + u*uvx) + v*uvy,
-    // ortho o = (u*uvx) + (v*uvy).
-    F3 col[kLanePx];
-    F3 row[kLanePx];
-    F3 fixed;   // persp: origin (eye); ortho: direction (-w)
+__device__ __forceinline__ void pixel_ray(const RenderParams& p, float ux, float uy, F3& o, F3& d) {
+    const F3 cu = mk3(p.u[0], p.u[1], p.u[2]);
+    const F3 cv = mk3(p.v[0], p.v[1], p.v[2]);
+    const F3 cw = mk3(p.w[0], p.w[1], p.w[2]);
+    if (PROJ == MRT_PROJ_PERSP) persp_ray(mk3(p.eye[0], p.eye[1], p.eye[2]), cu, cv, cw, p.focal, ux, uy, o, d);
+    else ortho_ray(cu, cv, cw, ux, uy, o, d);
+}
 
-    __device__ __forceinline__ void ray(int i, int j, F3& o, F3& d) const {
-        if (PROJ == MRT_PROJ_PERSP) {
-            o = fixed;
-            d = add3(col[i], row[j]);
-        } else {
-            o = add3(col[i], row[j]);
-            d = fixed;
+// Cooperative copy of one chunk of prefilter records into LDS.
+__device__ __forceinline__ void stage_chunk(float4* dst, const float4* __restrict__ src, int tid) {
+#pragma unroll
+    for (int k = 0; k < kChunkFloat4 / kBlockThreads; ++k)
+        dst[tid + k * kBlockThreads] = src[tid + k * kBlockThreads];
+}
+
+// Exact test of one primitive against the pixels of this lane's 4x4 block
+// whose bit is set in mask (bit r = row r/4, column r%4).  The closest hit so
+// far lives in the (t, id) planes in global memory -- each pixel belongs to
+// exactly one lane, so the read-modify-write needs no atomics -- which keeps
+// it out of the registers of the hot loop.  The loop runs until no lane of the
+// wave has a pixel left; lanes walk their own bits.
+template <int PROJ, bool TRI>
+__device__ __forceinline__ void exact_pass(const RenderParams& p, uint32_t mask, uint32_t prim, uint32_t x0,
+                                           uint32_t lr0, float* __restrict__ t_plane,
+                                           int32_t* __restrict__ id_plane, uint32_t pitch,
+                                           unsigned long long& n_exact) {
+    const float t_lower = 0.0f;   // scene::intersect, gfxraytrace.hpp:812
+    F3 A, B, C;
+    float radius = 0.0f;
+    if (TRI) {
+        const float4 va = p.tri_exact[(size_t)prim * 3 + 0];
+        const float4 vb = p.tri_exact[(size_t)prim * 3 + 1];
+        const float4 vc = p.tri_exact[(size_t)prim * 3 + 2];
+        A = mk3(va.x, va.y, va.z); B = mk3(vb.x, vb.y, vb.z); C = mk3(vc.x, vc.y, vc.z);
+    } else {
+        const float4 sp = p.sph[prim];
+        A = mk3(sp.x, sp.y, sp.z); B = A; C = A;
+        radius = sp.w;
+    }
+    const int32_t obj_id = (int32_t)(TRI ? p.n_sph + prim : prim);   // spheres first, gfxraytrace.hpp:701-714
+    const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
+    while (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
+        if (mask != 0) {
+            const uint32_t r = (uint32_t)__builtin_ctz(mask);
+            mask &= mask - 1;
+            const uint32_t x = x0 + (r & 3u), lr = lr0 + (r >> 2);
+            const uint32_t y = image_row(p, lr < last_row ? lr : last_row);
+            // gfxraytrace.hpp:850-852: pixel grid is (x + 1, y + 1) as floats.
+            const float ux = uv_component(p.left, p.right, (float)x + 1.0f, p.xres_f);
+            const float uy = uv_component(p.bottom, p.top, (float)y + 1.0f, p.yres_f);
+            F3 o, d;
+            pixel_ray<PROJ>(p, ux, uy, o, d);
+            const size_t off = (size_t)lr * pitch + x;
+            const float bound = t_plane[off];    // temp_max, kernel.cl:307,336
+            float t;
+            bool hit, two;
+            // tri_intersect / circle_intersect against the current bound
+            // (kernel.cl:324,341), then the loop's strict acceptance (:326,:344).
+            if (TRI) hit = tri_exact(A, B, C, o, d, bound, t_lower, t);
+            else hit = sphere_exact(A, radius, o, d, bound, t_lower, t, two);
+            if (hit && t > t_lower && t < bound) {
+                t_plane[off] = t;
+                id_plane[off] = obj_id;
+            }
+            ++n_exact;
         }
     }
-};
+}
 
 }  // namespace
 
@@ -64,7 +115,7 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const RenderParams
                                                              float* __restrict__ t_out,
                                                              int32_t* __restrict__ id_out,
                                                              uint32_t pitch) {
-    __shared__ float4 s_rec[kChunkTris * 3];
+    __shared__ float4 s_rec[kChunkFloat4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,104 +127,115 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const RenderParams
     const uint32_t wave_lr0 = blockIdx.y * kBlockTileY + (wave >> 1) * kWaveTile;
     const bool wave_active = (wave_x0 < p.xres) && (wave_lr0 < p.local_rows);
 
-    const F3 eye = mk3(p.eye[0], p.eye[1], p.eye[2]);
-    const F3 cu = mk3(p.u[0], p.u[1], p.u[2]);
-    const F3 cv = mk3(p.v[0], p.v[1], p.v[2]);
-    const F3 cw = mk3(p.w[0], p.w[1], p.w[2]);
-
-    // Pixel coordinates as floats for the prefilter, and the exact rays.
+    // Pixel coordinates as floats: all the prefilters need.
     const float xf = (float)x0;
     float yf[kLanePx];
-    RaySetup<PROJ> rs;
-    if (PROJ == MRT_PROJ_PERSP) rs.fixed = eye; else rs.fixed = mk3(-cw.x, -cw.y, -cw.z);
-    const F3 negwf = mk3(-cw.x * p.focal, -cw.y * p.focal, -cw.z * p.focal);
-#pragma unroll
-    for (int i = 0; i < kLanePx; ++i) {
-        // gfxraytrace.hpp:850-852: pixel grid is (x + 1, y + 1) as floats.
-        float ux = uv_component(p.left, p.right, (float)(x0 + i) + 1.0f, p.xres_f);
-        if (PROJ == MRT_PROJ_PERSP) rs.col[i] = add3(negwf, scale3(cu, ux));
-        else rs.col[i] = scale3(cu, ux);
-    }
 #pragma unroll
     for (int j = 0; j < kLanePx; ++j) {
-        uint32_t lr = lr0 + j;
-        uint32_t y = image_row(p, lr < p.local_rows ? lr : (p.local_rows ? p.local_rows - 1 : 0));
-        yf[j] = (float)y;
-        float uy = uv_component(p.bottom, p.top, (float)y + 1.0f, p.yres_f);
-        rs.row[j] = scale3(cv, uy);
+        const uint32_t lr = lr0 + j;
+        const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
+        yf[j] = (float)image_row(p, lr < last_row ? lr : last_row);
     }
 
-    // scene::intersect, gfxraytrace.hpp:812-813.
-    const float t_lower = 0.0f;
-    float best_t[kLanePx * kLanePx];
-    int32_t best_id[kLanePx * kLanePx];
+    // Closest hit so far: t = FLT_MAX (scene::intersect's upper bound,
+    // gfxraytrace.hpp:813), id = -1.  The planes are padded to whole block
+    // tiles, so no bounds checks: four aligned 16-byte row segments per plane.
+    if (wave_active) {
 #pragma unroll
-    for (int r = 0; r < kLanePx * kLanePx; ++r) { best_t[r] = FLT_MAX; best_id[r] = -1; }
+        for (int j = 0; j < kLanePx; ++j) {
+            const size_t off = (size_t)(lr0 + j) * pitch + x0;
+            *reinterpret_cast<float4*>(t_out + off) = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX);
+            *reinterpret_cast<int4*>(id_out + off) = make_int4(-1, -1, -1, -1);
+        }
+    }
 
     unsigned long long n_exact = 0;
-    const bool count_exact = p.exact_counter != nullptr;
+    const bool no_prefilter = (p.flags & 1u) != 0;
 
-    // ---- spheres: object ids 0 .. n_sph-1 (gfxraytrace.hpp:701-706) ----
-    if (wave_active) {
-        for (uint32_t s = 0; s < p.n_sph; ++s) {
-            const float4 sp = p.sph[s];
-            const F3 center = mk3(sp.x, sp.y, sp.z);
+    // ---- spheres: object ids 0 .. n_sph-1 ----
+    // Record (sx, ox, sy, oy): the pixel can only hit if
+    // (x*sx + ox)^2 + (y*sy + oy)^2 <= 1, an ellipse around the sphere's
+    // projected bounding box grown by the error margin.
+    for (uint32_t base = 0; base < p.n_sph_padded; base += kChunkFloat4) {
+        __syncthreads();
+        stage_chunk(s_rec, p.sph_filter + base, tid);
+        __syncthreads();
+        if (!wave_active) continue;
+        for (int g = 0; g < kChunkFloat4; g += kGroupSph) {
+            if (base + g >= p.n_sph) break;
+            float acc = 1.0f;
 #pragma unroll
-            for (int j = 0; j < kLanePx; ++j) {
+            for (int tt = 0; tt < kGroupSph; ++tt) {
+                const float4 e = s_rec[g + tt];
+                float dvm[kLanePx];
+#pragma unroll
+                for (int j = 0; j < kLanePx; ++j) {
+                    const float dv = __builtin_fmaf(yf[j], e.z, e.w);
+                    dvm[j] = __builtin_fmaf(dv, dv, -1.0f);
+                }
+                float du = __builtin_fmaf(xf, e.x, e.y);
 #pragma unroll
                 for (int i = 0; i < kLanePx; ++i) {
-                    const int r = j * kLanePx + i;
-                    F3 o, d;
-                    rs.ray(i, j, o, d);
-                    float a, b;
-                    float disc = sphere_disc(center, sp.w, o, d, a, b);
-                    if (!(disc < 0)) {
-                        float t = -b;
-                        if (disc > 0) t -= sqrtf(disc);
-                        t /= a;
-                        // circle_intersect's range test against the current
-                        // bound (kernel.cl:268,287) and the loop's own
-                        // acceptance (kernel.cl:344) are the same predicate.
-                        if (t < best_t[r] && t > t_lower) { best_t[r] = t; best_id[r] = (int32_t)s; }
-                        if (count_exact) ++n_exact;
-                    }
+#pragma unroll
+                    for (int j = 0; j < kLanePx; ++j) acc = __builtin_fminf(acc, __builtin_fmaf(du, du, dvm[j]));
+                    du += e.x;
                 }
+            }
+            const bool pass = (acc <= 0.0f) || no_prefilter;
+            if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
+
+            for (int tt = 0; tt < kGroupSph; ++tt) {
+                const uint32_t si = base + g + tt;
+                if (si >= p.n_sph) break;
+                const float4 e = s_rec[g + tt];
+                uint32_t mask = 0;
+                float du = __builtin_fmaf(xf, e.x, e.y);
+#pragma unroll
+                for (int i = 0; i < kLanePx; ++i) {
+#pragma unroll
+                    for (int j = 0; j < kLanePx; ++j) {
+                        const float dv = __builtin_fmaf(yf[j], e.z, e.w);
+                        if (__builtin_fmaf(du, du, __builtin_fmaf(dv, dv, -1.0f)) <= 0.0f) mask |= 1u << (j * kLanePx + i);
+                    }
+                    du += e.x;
+                }
+                if (no_prefilter) mask = 0xFFFFu;
+                exact_pass<PROJ, false>(p, mask, si, x0, lr0, t_out, id_out, pitch, n_exact);
             }
         }
     }
 
     // ---- triangles: object ids n_sph .. n_sph+n_tri-1 ----
-    const bool no_prefilter = (p.flags & 1u) != 0;
+    // Record: 12 floats (A0,B0,C0,A1 | B1,C1,A2,B2 | C2,-,-,-); edge k passes at
+    // pixel (x, y) when A_k*x + B_k*y + C_k >= 0.
     for (uint32_t base = 0; base < p.n_tri_padded; base += kChunkTris) {
         __syncthreads();
-        {
-            const float4* src = p.tri_filter + (size_t)base * 3;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) s_rec[tid + k * kBlockThreads] = src[tid + k * kBlockThreads];
-        }
+        stage_chunk(s_rec, p.tri_filter + (size_t)base * 3, tid);
         __syncthreads();
         if (!wave_active) continue;
 
         for (int g = 0; g < kChunkTris; g += kGroupTris) {
+            if (base + g >= p.n_tri) break;
             float acc = -1.0f;
 #pragma unroll
             for (int tt = 0; tt < kGroupTris; ++tt) {
-                const float4 e0 = s_rec[(g + tt) * 3 + 0];
-                const float4 e1 = s_rec[(g + tt) * 3 + 1];
-                const float4 e2 = s_rec[(g + tt) * 3 + 2];
-                const float c0 = __builtin_fmaf(e0.x, xf, e0.z);
-                const float c1 = __builtin_fmaf(e1.x, xf, e1.z);
-                const float c2 = __builtin_fmaf(e2.x, xf, e2.z);
+                const float4 q0 = s_rec[(g + tt) * 3 + 0];
+                const float4 q1 = s_rec[(g + tt) * 3 + 1];
+                const float cc2 = reinterpret_cast<const float*>(&s_rec[(g + tt) * 3 + 2])[0];
+                const float a0 = q0.x, b0 = q0.y, a1 = q0.w, b1 = q1.x, a2 = q1.z, b2 = q1.w;
+                const float c0 = __builtin_fmaf(a0, xf, q0.z);
+                const float c1 = __builtin_fmaf(a1, xf, q1.y);
+                const float c2 = __builtin_fmaf(a2, xf, cc2);
 #pragma unroll
                 for (int j = 0; j < kLanePx; ++j) {
-                    float v0 = __builtin_fmaf(e0.y, yf[j], c0);
-                    float v1 = __builtin_fmaf(e1.y, yf[j], c1);
-                    float v2 = __builtin_fmaf(e2.y, yf[j], c2);
+                    float v0 = __builtin_fmaf(b0, yf[j], c0);
+                    float v1 = __builtin_fmaf(b1, yf[j], c1);
+                    float v2 = __builtin_fmaf(b2, yf[j], c2);
 #pragma unroll
                     for (int i = 0; i < kLanePx; ++i) {
                         float m = __builtin_fminf(__builtin_fminf(v0, v1), v2);
                         acc = __builtin_fmaxf(acc, m);
-                        v0 += e0.x; v1 += e1.x; v2 += e2.x;
+                        v0 += a0; v1 += a1; v2 += a2;
                     }
                 }
             }
@@ -184,74 +246,46 @@ __global__ __launch_bounds__(kBlockThreads) void trace_kernel(const RenderParams
             for (int tt = 0; tt < kGroupTris; ++tt) {
                 const uint32_t ti = base + g + tt;
                 if (ti >= p.n_tri) break;
-                const float4 e0 = s_rec[(g + tt) * 3 + 0];
-                const float4 e1 = s_rec[(g + tt) * 3 + 1];
-                const float4 e2 = s_rec[(g + tt) * 3 + 2];
-                const float c0 = __builtin_fmaf(e0.x, xf, e0.z);
-                const float c1 = __builtin_fmaf(e1.x, xf, e1.z);
-                const float c2 = __builtin_fmaf(e2.x, xf, e2.z);
+                const float4 q0 = s_rec[(g + tt) * 3 + 0];
+                const float4 q1 = s_rec[(g + tt) * 3 + 1];
+                const float cc2 = reinterpret_cast<const float*>(&s_rec[(g + tt) * 3 + 2])[0];
+                const float a0 = q0.x, b0 = q0.y, a1 = q0.w, b1 = q1.x, a2 = q1.z, b2 = q1.w;
+                const float c0 = __builtin_fmaf(a0, xf, q0.z);
+                const float c1 = __builtin_fmaf(a1, xf, q1.y);
+                const float c2 = __builtin_fmaf(a2, xf, cc2);
                 uint32_t mask = 0;
 #pragma unroll
                 for (int j = 0; j < kLanePx; ++j) {
-                    float v0 = __builtin_fmaf(e0.y, yf[j], c0);
-                    float v1 = __builtin_fmaf(e1.y, yf[j], c1);
-                    float v2 = __builtin_fmaf(e2.y, yf[j], c2);
+                    float v0 = __builtin_fmaf(b0, yf[j], c0);
+                    float v1 = __builtin_fmaf(b1, yf[j], c1);
+                    float v2 = __builtin_fmaf(b2, yf[j], c2);
 #pragma unroll
                     for (int i = 0; i < kLanePx; ++i) {
                         float m = __builtin_fminf(__builtin_fminf(v0, v1), v2);
                         if (m >= 0.0f) mask |= 1u << (j * kLanePx + i);
-                        v0 += e0.x; v1 += e1.x; v2 += e2.x;
+                        v0 += a0; v1 += a1; v2 += a2;
                     }
                 }
                 if (no_prefilter) mask = 0xFFFFu;
-                if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
-
-                const float4 va = p.tri_exact[(size_t)ti * 3 + 0];
-                const float4 vb = p.tri_exact[(size_t)ti * 3 + 1];
-                const float4 vc = p.tri_exact[(size_t)ti * 3 + 2];
-                const F3 A = mk3(va.x, va.y, va.z), B = mk3(vb.x, vb.y, vb.z), C = mk3(vc.x, vc.y, vc.z);
-#pragma unroll
-                for (int j = 0; j < kLanePx; ++j) {
-#pragma unroll
-                    for (int i = 0; i < kLanePx; ++i) {
-                        const int r = j * kLanePx + i;
-                        if (mask & (1u << r)) {
-                            F3 o, d;
-                            rs.ray(i, j, o, d);
-                            float t;
-                            // tri_intersect with the current bound (kernel.cl:324),
-                            // then the loop's strict acceptance (kernel.cl:326).
-                            if (tri_exact(A, B, C, o, d, best_t[r], t_lower, t) && t > t_lower &&
-                                t < best_t[r]) {
-                                best_t[r] = t;
-                                best_id[r] = (int32_t)(p.n_sph + ti);
-                            }
-                            if (count_exact) ++n_exact;
-                        }
-                    }
-                }
+                exact_pass<PROJ, true>(p, mask, ti, x0, lr0, t_out, id_out, pitch, n_exact);
             }
         }
     }
 
     if (wave_active) {
-        // The (t, id) planes are padded to whole block tiles, so no bounds
-        // checks: each lane writes four aligned 16-byte row segments per plane.
+        // intersect.t_ of a miss is -1 (kernel.cl:363).
 #pragma unroll
         for (int j = 0; j < kLanePx; ++j) {
             const size_t off = (size_t)(lr0 + j) * pitch + x0;
-            float4 tv;
-            int4 iv;
-            tv.x = best_id[j * 4 + 0] < 0 ? -1.0f : best_t[j * 4 + 0];
-            tv.y = best_id[j * 4 + 1] < 0 ? -1.0f : best_t[j * 4 + 1];
-            tv.z = best_id[j * 4 + 2] < 0 ? -1.0f : best_t[j * 4 + 2];
-            tv.w = best_id[j * 4 + 3] < 0 ? -1.0f : best_t[j * 4 + 3];
-            iv.x = best_id[j * 4 + 0]; iv.y = best_id[j * 4 + 1];
-            iv.z = best_id[j * 4 + 2]; iv.w = best_id[j * 4 + 3];
+            float4 tv = *reinterpret_cast<const float4*>(t_out + off);
+            const int4 iv = *reinterpret_cast<const int4*>(id_out + off);
+            tv.x = iv.x < 0 ? -1.0f : tv.x;
+            tv.y = iv.y < 0 ? -1.0f : tv.y;
+            tv.z = iv.z < 0 ? -1.0f : tv.z;
+            tv.w = iv.w < 0 ? -1.0f : tv.w;
             *reinterpret_cast<float4*>(t_out + off) = tv;
-            *reinterpret_cast<int4*>(id_out + off) = iv;
         }
-        if (count_exact && n_exact) atomicAdd(p.exact_counter, n_exact);
+        if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
     }
 }
 

@@ -17,9 +17,16 @@ constexpr int kBlockThreads = 64 * kBlockWavesX * kBlockWavesY;   // 256
 constexpr int kBlockTileX = kWaveTile * kBlockWavesX;             // 64
 constexpr int kBlockTileY = kWaveTile * kBlockWavesY;             // 64
 
-// Triangles per LDS chunk and per any-lane-passes check.
+// Prefilter records are staged through LDS in chunks of kChunkFloat4 float4
+// (12 KiB): 256 triangle records of three float4, or 768 sphere records of
+// one.  kGroup* primitives are tested between two "does any lane pass?" votes.
 constexpr int kChunkTris = 256;
-constexpr int kGroupTris = 4;
+constexpr int kChunkFloat4 = kChunkTris * 3;
+#ifndef MRT_GROUP_TRIS
+#define MRT_GROUP_TRIS 4
+#endif
+constexpr int kGroupTris = MRT_GROUP_TRIS;
+constexpr int kGroupSph = 4;
 
 struct RenderParams {
     float eye[3], u[3], v[3], w[3];
@@ -34,7 +41,8 @@ struct RenderParams {
     uint32_t xres, yres;            // whole image
     uint32_t band_rows, rank, world;  // interleaved row-band partition
     uint32_t local_rows;            // rows this launch renders (packed)
-    uint32_t n_sph, n_tri, n_tri_padded, n_lights;
+    uint32_t n_sph, n_tri, n_tri_padded, n_sph_padded, n_lights;
+    const float4* sph_filter;       // 1 x float4 per sphere, padded to kChunkFloat4
     const float4* tri_filter;       // 3 x float4 per triangle, padded to kChunkTris
     const float4* tri_exact;        // 3 x float4 per triangle: (a, mat) (b, -) (c, -)
     const float4* sph;              // (cx, cy, cz, r)

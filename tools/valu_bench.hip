@@ -43,6 +43,23 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, fl
             if (KIND == 17) asm volatile("v_add3_u32 %0, %1, %2, %0" : "+v"(v[i]) : "v"(a), "v"(b));
             if (KIND == 18) asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(v[i]) : "v"(a), "v"(b));
             if (KIND == 19) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i]) : "s"(a), "v"(b));
+            if (KIND == 20) asm volatile("v_pk_add_f16 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 21) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(v[i]) : "v"(a), "v"(b));
+            if (KIND == 22) asm volatile("v_pk_min_f16 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 23) asm volatile("v_pk_max_f16 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 24) asm volatile("v_pk_add_i16 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 25) asm volatile("v_pk_min_i16 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 26) asm volatile("v_pk_max_i16 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 27) asm volatile("v_or_b32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 28) asm volatile("v_add_u32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 29) asm volatile("v_pk_mul_f16 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 30) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 31) asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(v[i]) : "v"(a), "v"(b));
+            if (KIND == 32) asm volatile("v_add_f32 %0, %1, %2" : "=v"(v[i]) : "v"(a), "v"(b));
+            if (KIND == 33) asm volatile("v_min_f16 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 34) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 35) asm volatile("v_max_i32 %0, %1, %0" : "+v"(v[i]) : "v"(a));
+            if (KIND == 36) asm volatile("v_pk_add_u16 %0, %1, %0" : "+v"(v[i]) : "v"(a));
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -89,7 +106,26 @@ int main() {
     float* d; unsigned long long* dc;
     CHECK(hipMalloc(&d, (size_t)ncu * 8 * 256 * 4));
     CHECK(hipMalloc(&dc, (size_t)ncu * 8 * 4 * 8));
-    for (int occ : {1, 2, 4}) {
+    for (int occ : {4}) {
+        run<20>("v_pk_add_f16", occ, d, dc, ncu);
+        run<31>("v_pk_add_f16 2src", occ, d, dc, ncu);
+        run<21>("v_pk_fma_f16", occ, d, dc, ncu);
+        run<29>("v_pk_mul_f16", occ, d, dc, ncu);
+        run<22>("v_pk_min_f16", occ, d, dc, ncu);
+        run<23>("v_pk_max_f16", occ, d, dc, ncu);
+        run<33>("v_min_f16", occ, d, dc, ncu);
+        run<24>("v_pk_add_i16", occ, d, dc, ncu);
+        run<36>("v_pk_add_u16", occ, d, dc, ncu);
+        run<25>("v_pk_min_i16", occ, d, dc, ncu);
+        run<26>("v_pk_max_i16", occ, d, dc, ncu);
+        run<27>("v_or_b32", occ, d, dc, ncu);
+        run<34>("v_xor_b32", occ, d, dc, ncu);
+        run<28>("v_add_u32", occ, d, dc, ncu);
+        run<35>("v_max_i32", occ, d, dc, ncu);
+        run<30>("v_cvt_pkrtz_f16_f32", occ, d, dc, ncu);
+        run<32>("v_add_f32 2src", occ, d, dc, ncu);
+    }
+    for (int occ : {4}) {
         run<0>("v_fma_f32 d=acc", occ, d, dc, ncu);
         run<15>("v_fma_f32 3 src", occ, d, dc, ncu);
         run<5>("v_fma_f32 sgpr", occ, d, dc, ncu);
