@@ -111,7 +111,7 @@ __device__ __forceinline__ void exact_pass(const RenderParams& p, uint32_t mask,
 }  // namespace
 
 template <int PROJ>
-__global__ __launch_bounds__(kBlockThreads) void trace_kernel(const RenderParams p,
+__global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace_kernel(const RenderParams p,
                                                              float* __restrict__ t_out,
                                                              int32_t* __restrict__ id_out,
                                                              uint32_t pitch) {

@@ -28,6 +28,13 @@ constexpr int kChunkFloat4 = kChunkTris * 3;
 constexpr int kGroupTris = MRT_GROUP_TRIS;
 constexpr int kGroupSph = 4;
 
+// Register budget of trace_kernel in waves per SIMD.  6 (<= 80 VGPRs) is what
+// the kernel needs without spilling; 8 (64 VGPRs, small spills in the exact
+// pass) measured the same on teatime 4K because the loop is VALU-issue bound.
+#ifndef MRT_TRACE_WAVES_PER_SIMD
+#define MRT_TRACE_WAVES_PER_SIMD 6
+#endif
+
 struct RenderParams {
     float eye[3], u[3], v[3], w[3];
     float left, right, top, bottom;
