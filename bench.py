@@ -10,8 +10,9 @@ primitive.  One step = one frame: ray generation, closest hit, shading, RGBA8
 bytes in HBM.  With N > 1 ranks (one process per GPU, launched by
 torch.distributed.run) the frame grows to 3840 x (2160*N) with the viewport's
 top/bottom scaled by N, so every rank still renders 2160 rows' worth of
-interleaved 64-row bands ("weak" scaling: fixed work per GPU), and the step
-includes gathering all bands to rank 0 over RCCL.
+interleaved 64-row bands ("weak" scaling: fixed work per GPU), and every step
+gathers all bands to rank 0 over RCCL; the gather of frame k runs on RCCL's
+stream while frame k+1 renders (two buffer sets).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel
 (trace_kernel): algorithmic FLOPs per launch = rays * (4032 * 45 + 2 * 20)
@@ -77,12 +78,40 @@ def cpu_baseline(sc, seconds_target=12.0):
     }
 
 
+def secondary_workloads(mrt, mkscene, ctx):
+    """Other BASELINE configurations on this one GPU, kernel time from HIP events (not the headline)."""
+    import torch
+    res = {}
+    cases = {
+        "teatime_8k_7680x4320": lambda: mrt.LoadedScene(text=mkscene.teatime(7680, 4320)).copy(),
+        "soup16k_16384x16384": lambda: mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy(),
+    }
+    for name, make in cases.items():
+        sc = make()
+        st = sc.struct
+        ctx.set_scene(sc)
+        buf = torch.empty(st.xres * st.yres * 4, dtype=torch.uint8, device="cuda")
+        ms = []
+        for _ in range(3):
+            s = ctx.render_bands_device(st.yres, 0, 1, buf.data_ptr(), buf.numel(), timed=True)
+            ms.append(s.kernel_ms)
+        best = min(ms)
+        rays = st.xres * st.yres
+        flops = rays * (st.n_tris * FLOPS_PER_TRI_TEST + st.n_spheres * FLOPS_PER_SPH_TEST)
+        res[name] = {"rays": rays, "primitives": st.n_spheres + st.n_tris, "kernel_ms": best,
+                     "mrays_per_s": rays / best * 1e-3, "prim_tests_per_s": rays * (st.n_spheres + st.n_tris) / best * 1e3,
+                     "algorithmic_tflops": flops / best * 1e-9, "frac_of_fp32_peak": flops / best * 1e-9 / FP32_PEAK_TFLOPS}
+        del buf
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the soup / 8K frames reported next to the headline")
     args = ap.parse_args()
 
     import torch          # before the HIP library: one HIP runtime per process
@@ -98,46 +127,68 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MRT_BENCH_REHEARSAL=1: every rank on GPU 0 and the gather over gloo through host
+    # memory -- only to exercise the N > 1 code path on a one-GPU box; the JSON says so.
+    rehearsal = os.environ.get("MRT_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     sc = build_scene(mrt, mkscene, world)
     st = sc.struct
-    ctx = mrt.Context(device=local_rank)
+    ctx = mrt.Context(device=dev_index)
     ctx.set_scene(sc)
     rows = mrt.band_rows(st.yres, BAND_ROWS, rank, world)
     row_bytes = st.xres * 4
     max_rows = max(mrt.band_rows(st.yres, BAND_ROWS, r, world) for r in range(world))
-    local = torch.empty(max_rows * row_bytes, dtype=torch.uint8, device=dev)
-    gathered = ([torch.empty(max_rows * row_bytes, dtype=torch.uint8, device=dev) for _ in range(world)]
-                if (world > 1 and rank == 0) else None)
+    # Two sets of buffers: the gather of frame k (RCCL, its own stream) overlaps the
+    # render of frame k+1; a buffer is reused only after its gather has completed.
+    gdev = torch.device("cpu") if rehearsal else dev
+    local = [torch.empty(max_rows * row_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+    gathered = [([torch.empty(max_rows * row_bytes, dtype=torch.uint8, device=gdev) for _ in range(world)]
+                 if (world > 1 and rank == 0) else None) for _ in range(2)]
+    works = [None, None]
     stream = torch.cuda.current_stream(dev)
 
-    def step():
-        ctx.render_bands_device(BAND_ROWS, rank, world, local.data_ptr(), local.numel(),
+    def step(k):
+        b = k & 1
+        if works[b] is not None:
+            works[b].wait()          # stream-level wait: frame k-2's gather is done with buffer b
+            works[b] = None
+        ctx.render_bands_device(BAND_ROWS, rank, world, local[b].data_ptr(), local[b].numel(),
                                 stream=stream.cuda_stream)
         if world > 1:
-            dist.gather(local, gathered, dst=0)
+            if rehearsal:
+                dist.gather(local[b].cpu(), gathered[b], dst=0)
+            else:
+                works[b] = dist.gather(local[b], gathered[b], dst=0, async_op=True)
 
     def fence():
+        for b in range(2):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -145,7 +196,7 @@ def main():
     trace_ms = []
     shade_ms = []
     for _ in range(max(10, min(args.steps, 50))):
-        s = ctx.render_bands_device(BAND_ROWS, rank, world, local.data_ptr(), local.numel(),
+        s = ctx.render_bands_device(BAND_ROWS, rank, world, local[0].data_ptr(), local[0].numel(),
                                     stream=stream.cuda_stream, timed=True)
         trace_ms.append(s.trace_ms)
         shade_ms.append(s.shade_ms)
@@ -168,7 +219,9 @@ def main():
             "config": {"workload": "teatime_4k" if world == 1 else f"teatime_3840x{st.yres}_bands{BAND_ROWS}",
                        "xres": st.xres, "yres": st.yres, "rays_per_step": total_rays,
                        "primitives": n_prims, "band_rows": BAND_ROWS,
-                       "gather": "rccl gather to rank 0" if world > 1 else "none",
+                       "gather": ("none" if world == 1 else
+                                  "REHEARSAL: all ranks on GPU 0, gloo gather through host memory" if rehearsal
+                                  else "rccl gather to rank 0"),
                        "output": "RGBA8 resident in HBM (no D2H in the timed region)"},
             "prim_tests_per_s": value * 1e6 * n_prims,
             "roofline": {
@@ -181,6 +234,18 @@ def main():
                         "executed FLOPs are lower (see DESIGN.md)",
             },
         }
+        if world == 1:
+            # What the CLI pays on top: the same frame into a pageable host buffer (PCIe D2H).
+            host_ms = []
+            for _ in range(5):
+                t1 = time.perf_counter()
+                _, hs = ctx.render()
+                host_ms.append((time.perf_counter() - t1) * 1e3)
+            out["host_frame"] = {"ms_per_frame": min(host_ms), "download_ms": hs.download_ms,
+                                 "mrays_per_s": total_rays / min(host_ms) * 1e-3,
+                                 "note": "mrt_render_rgba8 into pageable host memory; not the headline value"}
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_workloads(mrt, mkscene, ctx)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sc)
         print(json.dumps(out), flush=True)

@@ -126,6 +126,70 @@ def test_degenerate_and_edge_on_triangles(gpu_ctx, mrt, oracle):
         check(r["rgba"], o["rgba"], o["ids"])
 
 
+def _random_scene(mrt, rng, proj, xres, yres, n_tris, n_sph, skew=False):
+    """Random camera (any orientation, eye away from the origin) looking at a cloud of primitives."""
+    eye = rng.uniform(-50, 50, 3)
+    view = rng.normal(size=3)
+    view /= np.linalg.norm(view)
+    up = rng.normal(size=3)
+    u, v, w = scene_py.camera_basis(list(view), list(up))
+    u, v, w = np.array(u), np.array(v), np.array(w)
+    if skew:                       # not orthonormal: the API takes any basis
+        u = u + 0.2 * v
+        v = 1.3 * v + 0.1 * w
+    centre = eye + view * 6.0 if proj == mrt.PROJ_PERSP else view * 6.0   # the ortho origin ignores the eye
+    c = centre + rng.uniform(-3, 3, (n_tris, 3))
+    tri = np.concatenate([(c + rng.uniform(-0.6, 0.6, (n_tris, 3))).T for _ in range(3)], axis=0)
+    sc_ = centre + rng.uniform(-3, 3, (n_sph, 3))
+    sph = np.concatenate([sc_.T, rng.uniform(0.05, 0.5, (1, n_sph))], axis=0)
+    nm = 5
+    mat = np.concatenate([rng.uniform(0, 1, (3, nm)), rng.choice([1.0, 2.0, 4.0, 32.0], (1, nm))], axis=0)
+    light = np.concatenate([(centre + rng.uniform(-8, 8, (3, 3))).T, rng.uniform(0, 1, (3, 3))], axis=0)
+    return mrt.Scene(eye=eye, u=u, v=v, w=w, xres=xres, yres=yres, left=-1.2, right=0.9, top=0.7, bottom=-1.1,
+                     projection=proj, focal=rng.uniform(0.5, 2.0), shader=mrt.SHADER_PHONG, ka=0.1, kd=0.6,
+                     ks=0.3, ambient=(1, 0.9, 0.8), background=(0.05, 0.1, 0.2), sph=sph,
+                     sph_mat=rng.integers(0, nm, n_sph), tri=tri, tri_mat=rng.integers(0, nm, n_tris), mat=mat,
+                     light=light)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_random_cameras_match_oracle(gpu_ctx, mrt, oracle, seed):
+    """Arbitrary camera orientation and position, asymmetric viewport, non-square pixels, both
+    projections; seeds 13 and 14 use a basis that is not orthonormal."""
+    rng = np.random.default_rng(seed)
+    for proj in (mrt.PROJ_PERSP, mrt.PROJ_ORTHO):
+        sc = _random_scene(mrt, rng, proj, 200, 150, 400, 40, skew=seed >= 13)
+        o = oracle.render(sc, threads=8)
+        assert (o["ids"] >= 0).sum() > 1000
+        r = gpu_render(gpu_ctx, sc)
+        assert_same_hits(r, o)
+        check(r["rgba"], o["rgba"], o["ids"])
+
+
+def test_camera_inside_and_behind_geometry(gpu_ctx, mrt, oracle):
+    """Primitives that straddle or lie behind the eye plane, a sphere containing the eye, huge and
+    tiny primitives: the prefilter must stay a superset wherever its projection is unbounded."""
+    tri = np.array([
+        [-1, -1, -2,   1, -1, 3,    0, 1, 3],          # crosses the eye plane z = 0
+        [-5, -5, -1,   5, -5, -1,   0, 5, -1],         # entirely behind the camera
+        [-100, -100, 50, 100, -100, 50, 0, 100, 50],   # covers the whole view, far away
+        [0.1, 0.1, 1,  0.1001, 0.1, 1, 0.1, 0.1001, 1],  # far smaller than a pixel
+        [-0.5, 0.2, 0.05, 0.5, 0.2, 0.05, 0, 0.3, 0.05],  # very close to the eye
+    ], np.float32).T
+    sph = np.array([[0, 0, 0, 2.0], [0.3, 0.3, 4, 0.5], [0, 0, -3, 1.0], [2, 0, 0.2, 1.0],
+                    [0, 0, 30, 1e-3]], np.float32).T
+    for proj in (mrt.PROJ_PERSP, mrt.PROJ_ORTHO):
+        sc = mrt.Scene(eye=[0, 0, 0], u=[1, 0, 0], v=[0, -1, 0], w=[0, 0, -1], xres=160, yres=120, left=-1,
+                       right=1, top=1, bottom=-1, projection=proj, focal=1.0, shader=mrt.SHADER_PHONG, ka=0.1,
+                       kd=0.5, ks=0.3, ambient=(1, 1, 1), background=(0.1, 0.2, 0.3), tri=tri,
+                       tri_mat=[0, 1, 0, 1, 0], sph=sph, sph_mat=[1, 0, 1, 0, 1],
+                       mat=[[1, 0.2], [0.5, 0.9], [0.2, 0.1], [4, 16]], light=[[2], [2], [-1], [1], [1], [1]])
+        o = oracle.render(sc, threads=4)
+        r = gpu_render(gpu_ctx, sc)
+        assert_same_hits(r, o)
+        check(r["rgba"], o["rgba"], o["ids"])
+
+
 def test_empty_scene_and_no_lights(gpu_ctx, mrt, oracle):
     sc = mrt.Scene(eye=[0, 0, 0], u=[1, 0, 0], v=[0, -1, 0], w=[0, 0, -1], xres=70, yres=50, left=-1, right=1,
                    top=1, bottom=-1, projection=mrt.PROJ_PERSP, focal=1.0, shader=mrt.SHADER_PHONG, ka=0.3,
@@ -154,6 +218,36 @@ def test_teatime_4k_rows_against_oracle(gpu_ctx, mrt, oracle):
         assert np.array_equal(r["ids"][r0:r1], o["ids"][r0:r1])
         assert np.array_equal(r["t"][r0:r1], o["t"][r0:r1])
         check(r["rgba"][r0:r1], o["rgba"][r0:r1], o["ids"][r0:r1])
+
+
+def test_soup_all_primitives_against_oracle(gpu_ctx, mrt, oracle):
+    """The BASELINE soup (16 384 triangles + 1024 spheres, 8 lights) at 384x384: whole frame vs oracle."""
+    sc = mrt.LoadedScene(text=mkscene.soup(384, 384)).copy()
+    assert sc.struct.n_tris == 16384 and sc.struct.n_spheres == 1024 and sc.struct.n_lights == 8
+    o = oracle.render(sc, threads=16)
+    r = gpu_render(gpu_ctx, sc)
+    assert (o["ids"] >= 0).sum() > 10000
+    assert_same_hits(r, o)
+    check(r["rgba"], o["rgba"], o["ids"])
+
+
+def test_soup_16k_rows_against_oracle(mrt, oracle):
+    """BASELINE config 5 at full size, 16384 x 16384 (one GPU renders the whole frame here);
+    the oracle re-renders single rows."""
+    sc = mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy()
+    ctx = mrt.Context(device=0)
+    try:
+        ctx.set_scene(sc)
+        img, ids, t, st = ctx.render(want_ids=True)
+    finally:
+        ctx.close()
+    assert st.rays == 16384 * 16384
+    for y in (0, 5000, 8191, 16383):
+        o = oracle.render(sc, rows=(y, y + 1), threads=16)
+        assert np.array_equal(ids[y], o["ids"][y])
+        assert np.array_equal(t[y], o["t"][y])
+        check(img[y:y + 1], o["rgba"][y:y + 1], o["ids"][y:y + 1])
+    del img, ids, t
 
 
 def test_render_is_deterministic(gpu_ctx, mrt):
