@@ -82,6 +82,17 @@ def secondary_workloads(mrt, mkscene, ctx):
     """Other BASELINE configurations on this one GPU, kernel time from HIP events (not the headline)."""
     import torch
     res = {}
+    # The headline frame again with the opt-in 4x4 block reject and with no prefilter at all.
+    sc4k = mrt.LoadedScene(text=mkscene.teatime(XRES, YRES)).copy()
+    for label, flags, reps in (("teatime_4k_opt_in_block_reject", mrt.FLAG_BLOCK_REJECT, 5),
+                               ("teatime_4k_exact_test_only_no_prefilter", mrt.FLAG_NO_PREFILTER, 2)):
+        c2 = mrt.Context(device=torch.cuda.current_device(), flags=flags)
+        c2.set_scene(sc4k)
+        buf = torch.empty(XRES * YRES * 4, dtype=torch.uint8, device="cuda")
+        ms = [c2.render_bands_device(YRES, 0, 1, buf.data_ptr(), buf.numel(), timed=True).kernel_ms
+              for _ in range(reps)]
+        c2.close()
+        res[label] = {"kernel_ms": min(ms), "mrays_per_s": XRES * YRES / min(ms) * 1e-3}
     cases = {
         "teatime_8k_7680x4320": lambda: mrt.LoadedScene(text=mkscene.teatime(7680, 4320)).copy(),
         "soup16k_16384x16384": lambda: mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy(),

@@ -99,7 +99,12 @@ enum {
     MRT_FLAG_NO_PREFILTER = 1u << 0,
     /* Count the (pixel, primitive) pairs that reach the exact test into
      * mrt_stats.exact_tests (one atomic per wavefront; off by default). */
-    MRT_FLAG_COUNT_EXACT = 1u << 1
+    MRT_FLAG_COUNT_EXACT = 1u << 1,
+    /* Opt-in screen-space culling, off by default: before the per-pixel
+     * prefilter, reject a triangle for a lane's whole 4x4 pixel block when one
+     * of its edge functions is negative over the entire block.  Same pixels
+     * out; the default path tests every pixel against every primitive. */
+    MRT_FLAG_BLOCK_REJECT = 1u << 2
 };
 
 typedef struct mrt_stats {

@@ -18,6 +18,7 @@ PKG_DIR = Path(__file__).resolve().parent
 FLAG_NONE = 0
 FLAG_NO_PREFILTER = 1 << 0
 FLAG_COUNT_EXACT = 1 << 1
+FLAG_BLOCK_REJECT = 1 << 2
 PROJ_ORTHO, PROJ_PERSP = 0, 1
 SHADER_FLAT, SHADER_PHONG = 0, 1
 

@@ -118,12 +118,12 @@ struct Reader {
                 case 'r': out.push_back('\r'); break;
                 case 't': out.push_back('\t'); break;
                 case 'u': {
-                    uint32_t cp;
+                    uint32_t cp = 0;
                     if (!hex4(cp)) return false;
                     if (cp >= 0xD800 && cp <= 0xDBFF) {
                         if (end - p < 2 || p[0] != '\\' || p[1] != 'u') return fail("lone surrogate");
                         p += 2;
-                        uint32_t lo;
+                        uint32_t lo = 0;
                         if (!hex4(lo)) return false;
                         if (lo < 0xDC00 || lo > 0xDFFF) return fail("bad low surrogate");
                         cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);

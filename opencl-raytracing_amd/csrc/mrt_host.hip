@@ -18,7 +18,7 @@
 #include <vector>
 
 namespace mrt {
-template <int PROJ>
+template <int PROJ, bool BLOCK_REJECT>
 __global__ void trace_kernel(const RenderParams p, float* t_out, int32_t* id_out, uint32_t pitch);
 template <int PROJ>
 __global__ void shade_kernel(const RenderParams p, const float* t_in, const int32_t* id_in, uint32_t pitch);
@@ -120,10 +120,21 @@ struct Edge { float A, B, C; };
 
 // Triangle record as the kernel reads it from LDS: two 16-byte loads and one
 // 4-byte load, (A0,B0,C0,A1) (B1,C1,A2,B2) (C2,-,-,-).
+// The last three floats are the block-origin constants of the opt-in 4x4 block
+// reject: C'_k = C_k + 3*max(A_k,0) + 3*max(B_k,0), rounded up.
 void push_record(std::vector<float4>& rec, const Edge e[3]) {
+    float cb[3];
+    for (int k = 0; k < 3; ++k) {
+        const double span = 3.0 * std::fmax((double)e[k].A, 0.0) + 3.0 * std::fmax((double)e[k].B, 0.0);
+        double c = (double)e[k].C + span;
+        c += 4.0 / 16777216.0 * (std::fabs(c) + span) + 1e-30;
+        cb[k] = (float)c;
+        if ((double)cb[k] < c) cb[k] = std::nextafterf(cb[k], INFINITY);
+        if (!(std::fabs(cb[k]) < 1e30f)) cb[k] = cb[k] > 0 ? 1e30f : -1e30f;
+    }
     rec.push_back(make_float4(e[0].A, e[0].B, e[0].C, e[1].A));
     rec.push_back(make_float4(e[1].B, e[1].C, e[2].A, e[2].B));
-    rec.push_back(make_float4(e[2].C, 0.f, 0.f, 0.f));
+    rec.push_back(make_float4(e[2].C, cb[0], cb[1], cb[2]));
 }
 
 void push_const_record(std::vector<float4>& rec, float c) {
@@ -380,10 +391,18 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     const dim3 tgrid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY);
     const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
-    if (ctx->projection == MRT_PROJ_PERSP)
-        hipLaunchKernelGGL(mrt::trace_kernel<MRT_PROJ_PERSP>, tgrid, dim3(mrt::kBlockThreads), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+    // The block reject needs a lane's four rows to be consecutive image rows.
+    const bool block = (ctx->flags & MRT_FLAG_BLOCK_REJECT) && (band_rows % 4 == 0);
+    const bool persp = ctx->projection == MRT_PROJ_PERSP;
+    const dim3 tb(mrt::kBlockThreads);
+    if (persp && block)
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+    else if (persp)
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+    else if (block)
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
     else
-        hipLaunchKernelGGL(mrt::trace_kernel<MRT_PROJ_ORTHO>, tgrid, dim3(mrt::kBlockThreads), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
     HIP_TRY(ctx, hipGetLastError());
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     if (ctx->projection == MRT_PROJ_PERSP)

@@ -110,7 +110,7 @@ __device__ __forceinline__ void exact_pass(const RenderParams& p, uint32_t mask,
 
 }  // namespace
 
-template <int PROJ>
+template <int PROJ, bool BLOCK_REJECT>
 __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace_kernel(const RenderParams p,
                                                              float* __restrict__ t_out,
                                                              int32_t* __restrict__ id_out,
@@ -216,6 +216,25 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
 
         for (int g = 0; g < kChunkTris; g += kGroupTris) {
             if (base + g >= p.n_tri) break;
+            if (BLOCK_REJECT) {
+                // Opt-in (MRT_FLAG_BLOCK_REJECT): each edge function is monotone in x and
+                // in y, so its maximum over this lane's 4x4 block is its value at one
+                // corner; the record carries C'_k = C_k + 3*max(A_k,0) + 3*max(B_k,0), which
+                // moves that corner to the block origin.  If some edge is negative at its
+                // best corner, no pixel of the block passes and the per-pixel test is skipped.
+                float accb = -1.0f;
+#pragma unroll
+                for (int tt = 0; tt < kGroupTris; ++tt) {
+                    const float4 q0 = s_rec[(g + tt) * 3 + 0];
+                    const float4 q1 = s_rec[(g + tt) * 3 + 1];
+                    const float4 q2 = s_rec[(g + tt) * 3 + 2];
+                    const float m0 = __builtin_fmaf(q0.x, xf, __builtin_fmaf(q0.y, yf[0], q2.y));
+                    const float m1 = __builtin_fmaf(q0.w, xf, __builtin_fmaf(q1.x, yf[0], q2.z));
+                    const float m2 = __builtin_fmaf(q1.z, xf, __builtin_fmaf(q1.w, yf[0], q2.w));
+                    accb = __builtin_fmaxf(accb, __builtin_fminf(__builtin_fminf(m0, m1), m2));
+                }
+                if (__builtin_amdgcn_ballot_w64((accb >= 0.0f) || no_prefilter) == 0) continue;
+            }
             float acc = -1.0f;
 #pragma unroll
             for (int tt = 0; tt < kGroupTris; ++tt) {
@@ -362,8 +381,10 @@ __global__ __launch_bounds__(256) void shade_kernel(const RenderParams p,
     p.out[(size_t)lr * p.xres + x] = px;
 }
 
-template __global__ void trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_PERSP>(const RenderParams, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, false>(const RenderParams, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, false>(const RenderParams, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, true>(const RenderParams, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, true>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void shade_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float*, const int32_t*, uint32_t);
 template __global__ void shade_kernel<MRT_PROJ_PERSP>(const RenderParams, const float*, const int32_t*, uint32_t);
 

@@ -103,6 +103,42 @@ def test_prefilter_is_a_superset_of_exact(mrt, oracle):
         b.close()
 
 
+def test_block_reject_flag_changes_nothing(mrt, oracle):
+    """MRT_FLAG_BLOCK_REJECT (opt-in 4x4 block culling) must give the same winners, t and bytes
+    as the default path, including with band heights that are not multiples of 4."""
+    import torch
+    a = mrt.Context(device=0, flags=mrt.FLAG_COUNT_EXACT)
+    b = mrt.Context(device=0, flags=mrt.FLAG_BLOCK_REJECT | mrt.FLAG_COUNT_EXACT)
+    try:
+        rng = np.random.default_rng(5)
+        cases = [scene_py.load_scene(SCENES / "teatime.json", xres=1280, yres=720,
+                                     viewport=(-16 / 9, 16 / 9, 1.0, -1.0)),
+                 scene_py.load_scene(SCENES / "scene_gtri_ortho_phong.json"),
+                 mrt.LoadedScene(text=mkscene.soup(640, 480, 8192, 512, seed=3)).copy(),
+                 _random_scene(mrt, rng, mrt.PROJ_PERSP, 333, 222, 500, 50),
+                 _random_scene(mrt, rng, mrt.PROJ_ORTHO, 333, 222, 500, 50, skew=True)]
+        for sc in cases:
+            ra = gpu_render(a, sc)
+            rb = gpu_render(b, sc)
+            assert_same_hits(ra, rb)
+            assert np.array_equal(ra["rgba"], rb["rgba"])
+            assert rb["stats"].exact_tests == ra["stats"].exact_tests     # same survivors reach the exact test
+        # bands of 6 rows: the block path must step aside (a lane's rows are not consecutive)
+        sc = cases[0]
+        b.set_scene(sc)
+        full, _ = b.render()
+        rows = [mrt.band_rows(720, 6, r, 2) for r in range(2)]
+        stride = max(rows) * 1280 * 4
+        g = torch.zeros((2, stride), dtype=torch.uint8, device="cuda:0")
+        for r in range(2):
+            b.render_bands_device(6, r, 2, g[r].data_ptr(), stride)
+        torch.cuda.synchronize()
+        assert np.array_equal(mrt.bands_to_image(g.cpu().numpy(), stride, 1280, 720, 6, 2), full)
+    finally:
+        a.close()
+        b.close()
+
+
 def test_degenerate_and_edge_on_triangles(gpu_ctx, mrt, oracle):
     """Triangles the prefilter cannot orient (eye in the triangle's plane, zero
     area after rounding, parallel to an orthographic ray) must still match."""
@@ -164,6 +200,35 @@ def test_random_cameras_match_oracle(gpu_ctx, mrt, oracle, seed):
         r = gpu_render(gpu_ctx, sc)
         assert_same_hits(r, o)
         check(r["rgba"], o["rgba"], o["ids"])
+
+
+@pytest.mark.parametrize("offset", [3.0e3, 1.0e5])
+def test_far_from_origin_cancellation(gpu_ctx, mrt, oracle, offset):
+    """Scene translated far from the origin: a - o cancels catastrophically in FP32, the exact
+    test's determinants are noisy, and the prefilter's error margins have to cover that noise
+    (the filter must still be a superset of what the exact arithmetic accepts)."""
+    rng = np.random.default_rng(21)
+    shift = np.array([offset, -0.7 * offset, 0.4 * offset])
+    for proj in (mrt.PROJ_PERSP, mrt.PROJ_ORTHO):
+        base = _random_scene(mrt, rng, proj, 160, 120, 300, 30)
+        st = base.struct
+        eye = np.array(list(st.eye)) + shift
+        tri = base.tri.astype(np.float64).copy()
+        sph = base.sph.astype(np.float64).copy()
+        light = base.light.astype(np.float64).copy()
+        if proj == mrt.PROJ_PERSP:          # move camera and geometry together
+            for k in range(3):
+                tri[k::3] += shift[k]
+            sph[:3] += shift[:, None]
+            light[:3] += shift[:, None]
+        sc = mrt.Scene(eye=eye, u=list(st.u), v=list(st.v), w=list(st.w), xres=160, yres=120, left=st.left,
+                       right=st.right, top=st.top, bottom=st.bottom, projection=proj, focal=st.focal,
+                       shader=mrt.SHADER_FLAT, background=(0.05, 0.1, 0.2), sph=sph, sph_mat=base.sph_mat,
+                       tri=tri, tri_mat=base.tri_mat, mat=base.mat, light=light)
+        o = oracle.render(sc, threads=8)
+        r = gpu_render(gpu_ctx, sc)
+        assert_same_hits(r, o)
+        assert np.array_equal(r["rgba"], o["rgba"])
 
 
 def test_camera_inside_and_behind_geometry(gpu_ctx, mrt, oracle):
