@@ -3,8 +3,8 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric "Mrays/sec + ray-prim tests/sec vs FP32 peak,
-teatime 4K"): the teatime mesh (2 spheres + 4032 triangles, 2 lights,
+Workload (metric "Mrays/sec + ray-prim tests/sec vs FP32 peak, teatime 4K"):
+the teatime mesh (2 spheres + 4032 triangles, 2 lights,
 perspective, Blinn-Phong) at 3840x2160, every ray tested against every
 primitive.  One step = one frame: ray generation, closest hit, shading, RGBA8
 bytes in HBM.  With N > 1 ranks (one process per GPU, launched by
@@ -42,7 +42,7 @@ XRES, YRES = 3840, 2160
 
 
 def build_scene(mrt, mkscene, world):
-    """teatime at 3840 x (2160*world); world == 1 is the BASELINE 4K frame."""
+    """teatime at 3840 x (2160*world); world == 1 is the 4K benchmark frame."""
     text = mkscene.teatime(XRES, YRES)
     ls = mrt.LoadedScene(text=text)          # the product's own loader
     sc = ls.copy()
@@ -78,13 +78,34 @@ def cpu_baseline(sc, seconds_target=12.0):
     }
 
 
+def profiled_traffic():
+    """HBM bytes per trace_kernel launch from the committed rocprofv3 counter passes of this same
+    command (FETCH_SIZE and WRITE_SIZE are collected in separate --pmc runs, in KiB; on gfx950
+    FETCH_SIZE counts 16-byte-per-lane reads at half their size, hence the factor 2)."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*/teatime4k_pmc_summary.json")):
+        best = f
+    if best is None:
+        return None, None
+    try:
+        data = json.loads(best.read_text())
+        for name, entry in data.items():
+            if "trace_kernel" in name:
+                c = entry["counters_mean_per_launch"]
+                return c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024, str(best.relative_to(ROOT))
+    except (KeyError, ValueError):
+        pass
+    return None, None
+
+
 def secondary_workloads(mrt, mkscene, ctx):
-    """Other BASELINE configurations on this one GPU, kernel time from HIP events (not the headline)."""
+    """The other benchmark configurations on this one GPU, kernel time from HIP events (not the headline)."""
     import torch
     res = {}
     # The headline frame again with the opt-in 4x4 block reject and with no prefilter at all.
     sc4k = mrt.LoadedScene(text=mkscene.teatime(XRES, YRES)).copy()
     for label, flags, reps in (("teatime_4k_opt_in_block_reject", mrt.FLAG_BLOCK_REJECT, 5),
+                               ("teatime_4k_edge_test_only_no_circle", mrt.FLAG_NO_CIRCLE, 5),
                                ("teatime_4k_exact_test_only_no_prefilter", mrt.FLAG_NO_PREFILTER, 2)):
         c2 = mrt.Context(device=torch.cuda.current_device(), flags=flags)
         c2.set_scene(sc4k)
@@ -237,12 +258,14 @@ def main():
             "prim_tests_per_s": value * 1e6 * n_prims,
             "roofline": {
                 "bound": "valu", "kernel": "trace_kernel", "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
+                "traffic": profiled_traffic()[0] if world == 1 else None,
+                "traffic_source": profiled_traffic()[1] if world == 1 else None,
                 "kernel_ms": trace_avg, "shade_kernel_ms": shade_avg,
                 "flops_per_launch": flops_launch,
                 "note": "algorithmic FLOPs: 45 per ray-triangle test, 20 per ray-sphere test, every ray x "
                         "every primitive; the kernel rejects most pairs with a cheaper conservative test, so "
-                        "executed FLOPs are lower (see DESIGN.md)",
+                        "executed FLOPs are lower",
             },
         }
         if world == 1:

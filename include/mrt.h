@@ -104,7 +104,10 @@ enum {
      * prefilter, reject a triangle for a lane's whole 4x4 pixel block when one
      * of its edge functions is negative over the entire block.  Same pixels
      * out; the default path tests every pixel against every primitive. */
-    MRT_FLAG_BLOCK_REJECT = 1u << 2
+    MRT_FLAG_BLOCK_REJECT = 1u << 2,
+    /* Skip the per-pixel bounding-circle test that precedes the per-pixel
+     * edge-function test of a triangle (measurement aid; same pixels out). */
+    MRT_FLAG_NO_CIRCLE = 1u << 3
 };
 
 typedef struct mrt_stats {

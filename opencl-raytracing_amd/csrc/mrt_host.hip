@@ -41,6 +41,7 @@ struct mrt_ctx {
     // scene buffers
     void* d_sph_filter = nullptr;
     void* d_tri_filter = nullptr;
+    void* d_tri_circle = nullptr;
     void* d_tri_exact = nullptr;
     void* d_sph = nullptr;
     void* d_sph_mat = nullptr;
@@ -315,6 +316,80 @@ void build_sphere_records(const mrt_scene& s, std::vector<float4>& rec) {
     while (rec.size() % mrt::kChunkFloat4 != 0) rec.push_back(never);
 }
 
+// ---------------------------------------------------------------------------
+// Bounding circle of a triangle's prefilter region, (xc, yc, R^2, -).
+//
+// The region the three edge functions pass is the triangle whose sides are the
+// lines E_k = 0 of the record exactly as stored (floats, margins included).
+// Its corners are the pairwise intersections of those lines; the smallest
+// circle around them (diameter on the longest side when the third corner lies
+// inside, else the circumcircle), grown by a margin for the FP32 evaluation in
+// the kernel, therefore contains every pixel the edge test can pass.  Records
+// whose region is unbounded, degenerate or cannot be bounded reliably get a
+// circle every pixel passes; padding records get one no pixel passes.
+// ---------------------------------------------------------------------------
+void build_circle_records(const std::vector<float4>& rec, uint32_t n_tris, double xres, double yres,
+                          std::vector<float4>& circ) {
+    const float4 always = make_float4(0.f, 0.f, 1e30f, 0.f);
+    const float4 never = make_float4(0.f, 0.f, -1.0f, 0.f);
+    const size_t n_padded = rec.size() / 3;
+    circ.assign(n_padded, never);
+    for (size_t k = 0; k < n_tris; ++k) {
+        const float4 q0 = rec[3 * k], q1 = rec[3 * k + 1], q2 = rec[3 * k + 2];
+        const double A[3] = {q0.x, q0.w, q1.z}, B[3] = {q0.y, q1.x, q1.w}, C[3] = {q0.z, q1.y, q2.x};
+        circ[k] = always;
+        bool ok = true;
+        double px[3], py[3];
+        for (int e = 0; e < 3 && ok; ++e) {
+            const int i = e, j = (e + 1) % 3, o = (e + 2) % 3;
+            const double det = A[i] * B[j] - A[j] * B[i];
+            if (!(std::fabs(det) > 1e-9)) { ok = false; break; }
+            px[e] = (B[i] * C[j] - B[j] * C[i]) / det;
+            py[e] = (A[j] * C[i] - A[i] * C[j]) / det;
+            // the corner must satisfy the third inequality, or the region is not a bounded triangle
+            const double third = A[o] * px[e] + B[o] * py[e] + C[o];
+            if (!(third >= -1e-6 * (std::fabs(A[o] * px[e]) + std::fabs(B[o] * py[e]) + std::fabs(C[o]) + 1.0))) ok = false;
+            if (!std::isfinite(px[e]) || !std::isfinite(py[e])) ok = false;
+        }
+        if (!ok) continue;
+        // smallest enclosing circle of three points
+        double best_d2 = -1; int bi = 0, bj = 1;
+        for (int i = 0; i < 3; ++i) {
+            const int j = (i + 1) % 3;
+            const double d2 = (px[i] - px[j]) * (px[i] - px[j]) + (py[i] - py[j]) * (py[i] - py[j]);
+            if (d2 > best_d2) { best_d2 = d2; bi = i; bj = j; }
+        }
+        const int bk = 3 - bi - bj;
+        double cx = 0.5 * (px[bi] + px[bj]), cy = 0.5 * (py[bi] + py[bj]);
+        double r = 0.5 * std::sqrt(best_d2);
+        const double dk = std::hypot(px[bk] - cx, py[bk] - cy);
+        if (dk > r) {
+            // circumcircle
+            const double ax = px[0], ay = py[0], bx = px[1], by = py[1], cx2 = px[2], cy2 = py[2];
+            const double d = 2.0 * (ax * (by - cy2) + bx * (cy2 - ay) + cx2 * (ay - by));
+            if (std::fabs(d) > 1e-300) {
+                const double a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx2 * cx2 + cy2 * cy2;
+                cx = (a2 * (by - cy2) + b2 * (cy2 - ay) + c2 * (ay - by)) / d;
+                cy = (a2 * (cx2 - bx) + b2 * (ax - cx2) + c2 * (bx - ax)) / d;
+                r = 0.0;
+                for (int i = 0; i < 3; ++i) r = std::fmax(r, std::hypot(px[i] - cx, py[i] - cy));
+            } else {
+                cx = (px[0] + px[1] + px[2]) / 3.0; cy = (py[0] + py[1] + py[2]) / 3.0;
+                r = 0.0;
+                for (int i = 0; i < 3; ++i) r = std::fmax(r, std::hypot(px[i] - cx, py[i] - cy));
+            }
+        }
+        if (!std::isfinite(cx) || !std::isfinite(cy) || !std::isfinite(r)) continue;
+        // FP32 evaluation: x - xc and y - yc are rounded at the magnitude of the larger
+        // operand, then squared; cover that and the rounding of the record itself.
+        const double reach = std::fabs(cx) + std::fabs(cy) + xres + yres + r;
+        r += 0.5 + 32.0 / 16777216.0 * reach;
+        const double r2 = r * r * (1.0 + 1e-5);
+        if (!(r2 < 1e29) || std::fabs(cx) > 1e15 || std::fabs(cy) > 1e15) continue;
+        circ[k] = make_float4((float)cx, (float)cy, (float)r2, 0.f);
+    }
+}
+
 int check_scene(mrt_ctx* ctx, const mrt_scene* s) {
     if (!s) return fail(ctx, MRT_ERR_INVALID, "scene is NULL");
     if (s->xres == 0 || s->yres == 0) return fail(ctx, MRT_ERR_INVALID, "resolution must be positive");
@@ -479,7 +554,7 @@ void mrt_destroy(mrt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    free_dev(ctx->d_sph_filter); free_dev(ctx->d_tri_filter); free_dev(ctx->d_tri_exact); free_dev(ctx->d_sph);
+    free_dev(ctx->d_sph_filter); free_dev(ctx->d_tri_filter); free_dev(ctx->d_tri_circle); free_dev(ctx->d_tri_exact); free_dev(ctx->d_sph);
     free_dev(ctx->d_sph_mat); free_dev(ctx->d_mats); free_dev(ctx->d_lights);
     if (ctx->d_t) (void)hipFree(ctx->d_t);
     if (ctx->d_id) (void)hipFree(ctx->d_id);
@@ -501,6 +576,8 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     std::vector<float4> filt, sfilt;
     build_filter_records(*s, filt);
     build_sphere_records(*s, sfilt);
+    std::vector<float4> circ;
+    build_circle_records(filt, s->n_tris, s->xres, s->yres, circ);
     std::vector<float4> exact((size_t)s->n_tris * 3);
     for (uint32_t k = 0; k < s->n_tris; ++k) {
         float mbits;
@@ -527,6 +604,7 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
 
     if ((rc = upload(ctx, ctx->d_sph_filter, sfilt)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_tri_filter, filt)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_tri_circle, circ)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_tri_exact, exact)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_sph, sph)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_sph_mat, sph_mat)) != MRT_OK) return rc;
@@ -556,6 +634,7 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     p.n_tri_padded = (uint32_t)(filt.size() / 3);
     p.n_sph_padded = (uint32_t)sfilt.size();
     p.sph_filter = (const float4*)ctx->d_sph_filter;
+    p.tri_circle = (const float4*)ctx->d_tri_circle;
     p.n_lights = s->n_lights;
     p.tri_filter = (const float4*)ctx->d_tri_filter;
     p.tri_exact = (const float4*)ctx->d_tri_exact;

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                                                              int32_t* __restrict__ id_out,
                                                              uint32_t pitch) {
     __shared__ float4 s_rec[kChunkFloat4];
+    __shared__ float4 s_circ[kChunkTris];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     }
 
     unsigned long long n_exact = 0;
-    const bool no_prefilter = (p.flags & 1u) != 0;
+    const bool no_prefilter = (p.flags & MRT_FLAG_NO_PREFILTER) != 0;
+    const bool use_circle = (p.flags & (MRT_FLAG_NO_PREFILTER | MRT_FLAG_NO_CIRCLE)) == 0;
 
     // ---- spheres: object ids 0 .. n_sph-1 ----
     // Record (sx, ox, sy, oy): the pixel can only hit if
@@ -211,10 +213,37 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     for (uint32_t base = 0; base < p.n_tri_padded; base += kChunkTris) {
         __syncthreads();
         stage_chunk(s_rec, p.tri_filter + (size_t)base * 3, tid);
+        static_assert(kChunkTris == kBlockThreads, "one circle record per thread");
+        s_circ[tid] = p.tri_circle[base + tid];
         __syncthreads();
         if (!wave_active) continue;
 
-        for (int g = 0; g < kChunkTris; g += kGroupTris) {
+        for (int gc = 0; gc < kChunkTris; gc += kGroupCircle) {
+        if (base + gc >= p.n_tri) break;
+        if (use_circle) {
+            // First rejection, per pixel: squared distance to the centre of a circle
+            // that contains everything the three edge functions can pass, (xc, yc, R^2).
+            float accc = 1.0f;
+#pragma unroll
+            for (int tt = 0; tt < kGroupCircle; ++tt) {
+                const float4 c = s_circ[gc + tt];
+                float dvm[kLanePx];
+#pragma unroll
+                for (int j = 0; j < kLanePx; ++j) {
+                    const float dv = yf[j] - c.y;
+                    dvm[j] = __builtin_fmaf(dv, dv, -c.z);
+                }
+                const float du0 = xf - c.x;
+#pragma unroll
+                for (int i = 0; i < kLanePx; ++i) {
+                    const float du = du0 + (float)i;
+#pragma unroll
+                    for (int j = 0; j < kLanePx; ++j) accc = __builtin_fminf(accc, __builtin_fmaf(du, du, dvm[j]));
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(accc <= 0.0f) == 0) continue;
+        }
+        for (int g = gc; g < gc + kGroupCircle; g += kGroupTris) {
             if (base + g >= p.n_tri) break;
             if (BLOCK_REJECT) {
                 // Opt-in (MRT_FLAG_BLOCK_REJECT): each edge function is monotone in x and
@@ -288,6 +317,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                 if (no_prefilter) mask = 0xFFFFu;
                 exact_pass<PROJ, true>(p, mask, ti, x0, lr0, t_out, id_out, pitch, n_exact);
             }
+        }
         }
     }
 

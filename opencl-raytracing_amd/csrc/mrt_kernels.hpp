@@ -27,6 +27,7 @@ constexpr int kChunkFloat4 = kChunkTris * 3;
 #endif
 constexpr int kGroupTris = MRT_GROUP_TRIS;
 constexpr int kGroupSph = 4;
+constexpr int kGroupCircle = 8;   // triangles per vote of the bounding-circle test (a multiple of kGroupTris)
 
 // Register budget of trace_kernel in waves per SIMD.  6 (<= 80 VGPRs) is what
 // the kernel needs without spilling; 8 (64 VGPRs, small spills in the exact
@@ -51,6 +52,7 @@ struct RenderParams {
     uint32_t n_sph, n_tri, n_tri_padded, n_sph_padded, n_lights;
     const float4* sph_filter;       // 1 x float4 per sphere, padded to kChunkFloat4
     const float4* tri_filter;       // 3 x float4 per triangle, padded to kChunkTris
+    const float4* tri_circle;       // (xc, yc, R^2, -) per triangle, padded to kChunkTris
     const float4* tri_exact;        // 3 x float4 per triangle: (a, mat) (b, -) (c, -)
     const float4* sph;              // (cx, cy, cz, r)
     const uint32_t* sph_mat;

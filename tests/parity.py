@@ -1,4 +1,4 @@
-"""Shared parity criterion (BASELINE north_star): <= 1 LSB per 8-bit channel on
+"""Shared parity criterion: <= 1 LSB per 8-bit channel on
 >= 99.9 % of pixels; every other pixel must lie on a primitive / silhouette
 edge, i.e. have an 8-neighbour whose winning object id differs in the oracle."""
 import numpy as np

@@ -1,7 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU
 oracle and the committed golden fixtures.
 
-Tolerance (BASELINE north_star): <= 1 LSB per 8-bit channel on >= 99.9 % of
+Tolerance: <= 1 LSB per 8-bit channel on >= 99.9 % of
 pixels, the rest confined to primitive / silhouette edges (tests/parity.py).
 Hit/miss decisions, winners and t are integer / decision work and are held to
 the stricter bar: identical to the oracle's, bit for bit, because the device
@@ -104,11 +104,13 @@ def test_prefilter_is_a_superset_of_exact(mrt, oracle):
 
 
 def test_block_reject_flag_changes_nothing(mrt, oracle):
-    """MRT_FLAG_BLOCK_REJECT (opt-in 4x4 block culling) must give the same winners, t and bytes
-    as the default path, including with band heights that are not multiples of 4."""
+    """MRT_FLAG_BLOCK_REJECT (opt-in 4x4 block culling) and MRT_FLAG_NO_CIRCLE (no bounding-circle
+    level) must give the same winners, t and bytes as the default path, including with band
+    heights that are not multiples of 4."""
     import torch
     a = mrt.Context(device=0, flags=mrt.FLAG_COUNT_EXACT)
     b = mrt.Context(device=0, flags=mrt.FLAG_BLOCK_REJECT | mrt.FLAG_COUNT_EXACT)
+    c = mrt.Context(device=0, flags=mrt.FLAG_NO_CIRCLE | mrt.FLAG_COUNT_EXACT)
     try:
         rng = np.random.default_rng(5)
         cases = [scene_py.load_scene(SCENES / "teatime.json", xres=1280, yres=720,
@@ -123,6 +125,10 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
             assert_same_hits(ra, rb)
             assert np.array_equal(ra["rgba"], rb["rgba"])
             assert rb["stats"].exact_tests == ra["stats"].exact_tests     # same survivors reach the exact test
+            rc = gpu_render(c, sc)                                        # without the bounding-circle level
+            assert_same_hits(ra, rc)
+            assert np.array_equal(ra["rgba"], rc["rgba"])
+            assert rc["stats"].exact_tests == ra["stats"].exact_tests
         # bands of 6 rows: the block path must step aside (a lane's rows are not consecutive)
         sc = cases[0]
         b.set_scene(sc)
@@ -137,6 +143,7 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
     finally:
         a.close()
         b.close()
+        c.close()
 
 
 def test_degenerate_and_edge_on_triangles(gpu_ctx, mrt, oracle):
@@ -273,7 +280,7 @@ def test_empty_scene_and_no_lights(gpu_ctx, mrt, oracle):
 
 
 def test_teatime_4k_rows_against_oracle(gpu_ctx, mrt, oracle):
-    """Full BASELINE size on the GPU; the oracle re-renders a few row ranges
+    """The full 3840x2160 benchmark frame on the GPU; the oracle re-renders a few row ranges
     (bounded CPU time) including the mesh."""
     ls = mrt.LoadedScene(text=mkscene.teatime(3840, 2160)).copy()
     r = gpu_render(gpu_ctx, ls)
@@ -286,7 +293,7 @@ def test_teatime_4k_rows_against_oracle(gpu_ctx, mrt, oracle):
 
 
 def test_soup_all_primitives_against_oracle(gpu_ctx, mrt, oracle):
-    """The BASELINE soup (16 384 triangles + 1024 spheres, 8 lights) at 384x384: whole frame vs oracle."""
+    """The benchmark soup (16 384 triangles + 1024 spheres, 8 lights) at 384x384: whole frame vs oracle."""
     sc = mrt.LoadedScene(text=mkscene.soup(384, 384)).copy()
     assert sc.struct.n_tris == 16384 and sc.struct.n_spheres == 1024 and sc.struct.n_lights == 8
     o = oracle.render(sc, threads=16)
@@ -297,7 +304,7 @@ def test_soup_all_primitives_against_oracle(gpu_ctx, mrt, oracle):
 
 
 def test_soup_16k_rows_against_oracle(mrt, oracle):
-    """BASELINE config 5 at full size, 16384 x 16384 (one GPU renders the whole frame here);
+    """The 16384 x 16384 soup benchmark frame at full size (one GPU renders the whole frame here);
     the oracle re-renders single rows."""
     sc = mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy()
     ctx = mrt.Context(device=0)
