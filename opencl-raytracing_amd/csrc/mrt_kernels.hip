@@ -213,14 +213,29 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     for (uint32_t base = 0; base < p.n_tri_padded; base += kChunkTris) {
         __syncthreads();
         stage_chunk(s_rec, p.tri_filter + (size_t)base * 3, tid);
-        static_assert(kChunkTris == kBlockThreads, "one circle record per thread");
-        s_circ[tid] = p.tri_circle[base + tid];
+#pragma unroll
+        for (int k = 0; k < kChunkTris / kBlockThreads; ++k)
+            s_circ[tid + k * kBlockThreads] = p.tri_circle[base + tid + k * kBlockThreads];
         __syncthreads();
         if (!wave_active) continue;
 
         for (int gc = 0; gc < kChunkTris; gc += kGroupCircle) {
         if (base + gc >= p.n_tri) break;
-        if (use_circle) {
+        if (use_circle && BLOCK_REJECT) {
+            // Opt-in block form of the circle test: the point of this lane's 4x4 block
+            // nearest to the centre, per axis, is the centre's coordinate clamped to the
+            // block's range; if even that point is outside the circle, every pixel is.
+            float accc = 1.0f;
+#pragma unroll
+            for (int tt = 0; tt < kGroupCircle; ++tt) {
+                const float4 c = s_circ[gc + tt];
+                const float du0 = xf - c.x, dv0 = yf[0] - c.y;
+                const float du = __builtin_amdgcn_fmed3f(du0, du0 + 3.0f, 0.0f);
+                const float dv = __builtin_amdgcn_fmed3f(dv0, dv0 + 3.0f, 0.0f);
+                accc = __builtin_fminf(accc, __builtin_fmaf(du, du, __builtin_fmaf(dv, dv, -c.z)));
+            }
+            if (__builtin_amdgcn_ballot_w64(accc <= 0.0f) == 0) continue;
+        } else if (use_circle) {
             // First rejection, per pixel: squared distance to the centre of a circle
             // that contains everything the three edge functions can pass, (xc, yc, R^2).
             float accc = 1.0f;

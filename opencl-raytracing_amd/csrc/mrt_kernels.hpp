@@ -12,7 +12,10 @@ namespace mrt {
 // lane's row segment is one aligned 16-byte RGBA8 store.
 constexpr int kLanePx = 4;                 // pixels per lane, per axis
 constexpr int kWaveTile = 8 * kLanePx;     // 32
-constexpr int kBlockWavesX = 2, kBlockWavesY = 2;
+#ifndef MRT_BLOCK_WAVES_Y
+#define MRT_BLOCK_WAVES_Y 2
+#endif
+constexpr int kBlockWavesX = 2, kBlockWavesY = MRT_BLOCK_WAVES_Y;
 constexpr int kBlockThreads = 64 * kBlockWavesX * kBlockWavesY;   // 256
 constexpr int kBlockTileX = kWaveTile * kBlockWavesX;             // 64
 constexpr int kBlockTileY = kWaveTile * kBlockWavesY;             // 64
@@ -27,7 +30,10 @@ constexpr int kChunkFloat4 = kChunkTris * 3;
 #endif
 constexpr int kGroupTris = MRT_GROUP_TRIS;
 constexpr int kGroupSph = 4;
-constexpr int kGroupCircle = 8;   // triangles per vote of the bounding-circle test (a multiple of kGroupTris)
+#ifndef MRT_GROUP_CIRCLE
+#define MRT_GROUP_CIRCLE 8
+#endif
+constexpr int kGroupCircle = MRT_GROUP_CIRCLE;   // triangles per vote of the bounding-circle test (a multiple of kGroupTris)
 
 // Register budget of trace_kernel in waves per SIMD.  6 (<= 80 VGPRs) is what
 // the kernel needs without spilling; 8 (64 VGPRs, small spills in the exact

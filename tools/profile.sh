@@ -10,7 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+CMD="python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary"
 
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1
 echo "trace exit $?"

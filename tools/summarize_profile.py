@@ -1,0 +1,50 @@
+"""Condenses a tools/profile.sh output directory (gpurun_out/prof_<tag>/) into the files that
+are committed under profiles/<round>/: the rocprofv3 kernel-stats CSV as is, plus the mean per
+launch of every hardware counter for the render kernels (CSV and JSON).
+
+Usage: python tools/summarize_profile.py gpurun_out/prof_r1b profiles/r1
+"""
+import collections
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+
+def main(src, dst):
+    src, dst = Path(src), Path(dst)
+    dst.mkdir(parents=True, exist_ok=True)
+    shutil.copy(src / "trace" / "trace_kernel_stats.csv", dst / "teatime4k_kernel_stats.csv")
+    out = {}
+    for d in sorted(src.glob("pmc_*")):
+        f = d / "pmc_counter_collection.csv"
+        if not f.is_file():
+            continue
+        agg = collections.defaultdict(list)
+        meta = {}
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "mrt::" not in k:
+                continue
+            agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            meta[k] = {x: r[x] for x in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size")}
+        for (k, c), v in sorted(agg.items()):
+            e = out.setdefault(k, {"dispatch": meta[k], "counters_mean_per_launch": {}, "launches": len(v)})
+            e["counters_mean_per_launch"][c] = sum(v) / len(v)
+    (dst / "teatime4k_pmc_summary.json").write_text(json.dumps(out, indent=1))
+    with open(dst / "teatime4k_pmc_summary.csv", "w") as f:
+        f.write("kernel,counter,mean_per_launch\n")
+        for k, d in out.items():
+            for c, v in d["counters_mean_per_launch"].items():
+                f.write(f"\"{k}\",{c},{v:.6g}\n")
+    print((dst / "teatime4k_kernel_stats.csv").read_text())
+    for k, d in out.items():
+        if "trace" in k:
+            print(k, d["dispatch"])
+            for c, v in d["counters_mean_per_launch"].items():
+                print(f"  {c:28s} {v:.6g}")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:3])
