@@ -141,6 +141,23 @@ int mrt_abi_version(void);
  * gfxraytrace.hpp:727-828. */
 int mrt_set_scene(mrt_ctx *ctx, const mrt_scene *scene);
 
+/* Camera, viewport and projection of a frame: the fields of mrt_scene that
+ * change when only the view changes. */
+typedef struct mrt_camera {
+    float eye[3], u[3], v[3], w[3];
+    uint32_t xres, yres;
+    float left, right, top, bottom;
+    int32_t projection;                 /* MRT_PROJ_*                            */
+    float focal;
+} mrt_camera;
+
+/* Replace the view of the scene last given to mrt_set_scene: geometry,
+ * materials, lights and shader stay on the GPU, only the per-view records
+ * are rebuilt.  Waits for frames still in flight on this device.  The
+ * reference has no equivalent: it re-creates context, program and buffers in
+ * every stage call (CLHelpers.hpp:79,119,155,196,242,281). */
+int mrt_set_camera(mrt_ctx *ctx, const mrt_camera *camera);
+
 /* Render the whole frame into host memory: xres*yres RGBA8, row-major, pixel
  * (x, y) at 4*(y*xres + x), A = 255.  Bytes are unsigned(x * 255.0f) of the
  * shaded float colour (gfximage.hpp:46-51).  Replaces gfx::scene::render()

@@ -25,7 +25,7 @@ SHADER_FLAT, SHADER_PHONG = 0, 1
 
 # Every symbol include/mrt.h declares.
 EXPORTED_SYMBOLS = [
-    "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_abi_version", "mrt_set_scene",
+    "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_abi_version", "mrt_set_scene", "mrt_set_camera",
     "mrt_render_rgba8", "mrt_render_debug", "mrt_band_rows", "mrt_render_bands_device",
     "mrt_bands_to_image", "mrt_scene_load_file", "mrt_scene_load_text", "mrt_scene_view",
     "mrt_scene_info_view", "mrt_scene_free", "mrt_write_png_rgb", "mrt_stage_uv",
@@ -50,6 +50,16 @@ class SceneStruct(C.Structure):
         ("n_tris", C.c_uint32), ("tri", _fp * 9), ("tri_mat", _up),
         ("n_materials", C.c_uint32), ("mat", _fp * 4),
         ("n_lights", C.c_uint32), ("light", _fp * 6),
+    ]
+
+
+class CameraStruct(C.Structure):
+    """mrt_camera."""
+    _fields_ = [
+        ("eye", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+        ("xres", C.c_uint32), ("yres", C.c_uint32),
+        ("left", C.c_float), ("right", C.c_float), ("top", C.c_float), ("bottom", C.c_float),
+        ("projection", C.c_int32), ("focal", C.c_float),
     ]
 
 
@@ -148,6 +158,7 @@ def lib():
     L.mrt_last_error.argtypes = [vp]
     L.mrt_last_error.restype = C.c_char_p
     L.mrt_set_scene.argtypes = [vp, C.POINTER(SceneStruct)]
+    L.mrt_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
     L.mrt_render_rgba8.argtypes = [vp, vp, C.POINTER(Stats)]
     L.mrt_render_debug.argtypes = [vp, vp, vp, vp, C.POINTER(Stats)]
     L.mrt_band_rows.argtypes = [C.c_uint32] * 4
@@ -302,6 +313,17 @@ class Context:
     def set_scene(self, scene):
         st = scene.struct
         self._check(lib().mrt_set_scene(self._h, C.byref(st)))
+        self.xres, self.yres = st.xres, st.yres
+
+    def set_camera(self, scene):
+        """Takes the view (camera, viewport, projection) of `scene`, keeps everything else."""
+        st = scene.struct
+        cam = CameraStruct()
+        for name in ("eye", "u", "v", "w"):
+            setattr(cam, name, getattr(st, name))
+        for name in ("xres", "yres", "left", "right", "top", "bottom", "projection", "focal"):
+            setattr(cam, name, getattr(st, name))
+        self._check(lib().mrt_set_camera(self._h, C.byref(cam)))
         self.xres, self.yres = st.xres, st.yres
 
     def render(self, want_ids=False):

@@ -38,10 +38,16 @@ struct mrt_ctx {
     int projection = 0;
     double upload_ms = 0.0;
 
+    // Host copy of the geometry planes (the per-view prefilter records are rebuilt
+    // from them when only the camera changes) and the scene header they belong to.
+    std::vector<float> h_tri[9], h_sph[4];
+    mrt_scene h_scene{};
+
     // scene buffers
     void* d_sph_filter = nullptr;
     void* d_tri_filter = nullptr;
     void* d_tri_circle = nullptr;
+    size_t cap_sph_filter = 0, cap_tri_filter = 0, cap_tri_circle = 0;
     void* d_tri_exact = nullptr;
     void* d_sph = nullptr;
     void* d_sph_mat = nullptr;
@@ -81,6 +87,21 @@ int upload(mrt_ctx* ctx, void*& dst, const std::vector<T>& src) {
     free_dev(dst);
     size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
     HIP_TRY(ctx, hipMalloc(&dst, bytes));
+    if (!src.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return MRT_OK;
+}
+
+// As upload(), but keeps the allocation when the size has not changed.
+template <typename T>
+int upload_reuse(mrt_ctx* ctx, void*& dst, size_t& cap_bytes, const std::vector<T>& src) {
+    const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+    if (!dst || cap_bytes != bytes) {
+        free_dev(dst);
+        cap_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&dst, bytes));
+        cap_bytes = bytes;
+    }
     if (!src.empty())
         HIP_TRY(ctx, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return MRT_OK;
@@ -565,6 +586,37 @@ void mrt_destroy(mrt_ctx* ctx) {
     delete ctx;
 }
 
+// Derives the per-view prefilter records from ctx->h_scene, uploads them and
+// refreshes the camera part of the kernel parameters.
+static int rebuild_view(mrt_ctx* ctx) {
+    const mrt_scene* s = &ctx->h_scene;
+    std::vector<float4> filt, sfilt, circ;
+    build_filter_records(*s, filt);
+    build_sphere_records(*s, sfilt);
+    build_circle_records(filt, s->n_tris, s->xres, s->yres, circ);
+    int rc;
+    if ((rc = upload_reuse(ctx, ctx->d_sph_filter, ctx->cap_sph_filter, sfilt)) != MRT_OK) return rc;
+    if ((rc = upload_reuse(ctx, ctx->d_tri_filter, ctx->cap_tri_filter, filt)) != MRT_OK) return rc;
+    if ((rc = upload_reuse(ctx, ctx->d_tri_circle, ctx->cap_tri_circle, circ)) != MRT_OK) return rc;
+    // The staging vectors are pageable and die with this call.
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    RenderParams& p = ctx->params;
+    for (int k = 0; k < 3; ++k) { p.eye[k] = s->eye[k]; p.u[k] = s->u[k]; p.v[k] = s->v[k]; p.w[k] = s->w[k]; }
+    p.left = s->left; p.right = s->right; p.top = s->top; p.bottom = s->bottom;
+    // viewport::to_struct (gfxraytrace.hpp:736-740) stores the resolution as floats.
+    p.xres_f = (float)s->xres; p.yres_f = (float)s->yres;
+    p.focal = s->focal;
+    p.xres = s->xres; p.yres = s->yres;
+    p.n_tri_padded = (uint32_t)(filt.size() / 3);
+    p.n_sph_padded = (uint32_t)sfilt.size();
+    p.sph_filter = (const float4*)ctx->d_sph_filter;
+    p.tri_filter = (const float4*)ctx->d_tri_filter;
+    p.tri_circle = (const float4*)ctx->d_tri_circle;
+    ctx->projection = s->projection;
+    return MRT_OK;
+}
+
 int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     if (!ctx) return MRT_ERR_INVALID;
     int rc = check_scene(ctx, s);
@@ -573,11 +625,21 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->have_scene = false;
 
-    std::vector<float4> filt, sfilt;
-    build_filter_records(*s, filt);
-    build_sphere_records(*s, sfilt);
-    std::vector<float4> circ;
-    build_circle_records(filt, s->n_tris, s->xres, s->yres, circ);
+    // Host copy of the header and of the geometry planes.
+    ctx->h_scene = *s;
+    for (int k = 0; k < 9; ++k) {
+        ctx->h_tri[k].assign(s->n_tris ? s->tri[k] : nullptr, s->n_tris ? s->tri[k] + s->n_tris : nullptr);
+        ctx->h_scene.tri[k] = ctx->h_tri[k].data();
+    }
+    for (int k = 0; k < 4; ++k) {
+        ctx->h_sph[k].assign(s->n_spheres ? s->sph[k] : nullptr, s->n_spheres ? s->sph[k] + s->n_spheres : nullptr);
+        ctx->h_scene.sph[k] = ctx->h_sph[k].data();
+    }
+    // Not needed for the per-view records; never dereferenced through h_scene.
+    ctx->h_scene.sph_mat = nullptr; ctx->h_scene.tri_mat = nullptr;
+    for (int k = 0; k < 4; ++k) ctx->h_scene.mat[k] = nullptr;
+    for (int k = 0; k < 6; ++k) ctx->h_scene.light[k] = nullptr;
+
     std::vector<float4> exact((size_t)s->n_tris * 3);
     for (uint32_t k = 0; k < s->n_tris; ++k) {
         float mbits;
@@ -602,47 +664,55 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
         lights[2 * (size_t)k + 1] = make_float4(s->light[3][k], s->light[4][k], s->light[5][k], 0.f);
     }
 
-    if ((rc = upload(ctx, ctx->d_sph_filter, sfilt)) != MRT_OK) return rc;
-    if ((rc = upload(ctx, ctx->d_tri_filter, filt)) != MRT_OK) return rc;
-    if ((rc = upload(ctx, ctx->d_tri_circle, circ)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_tri_exact, exact)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_sph, sph)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_sph_mat, sph_mat)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_mats, mats)) != MRT_OK) return rc;
     if ((rc = upload(ctx, ctx->d_lights, lights)) != MRT_OK) return rc;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    // The staging vectors above are pageable and die with this call.
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    float ms = 0.f;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-    ctx->upload_ms = ms;
 
     RenderParams& p = ctx->params;
     std::memset(&p, 0, sizeof p);
-    for (int k = 0; k < 3; ++k) {
-        p.eye[k] = s->eye[k]; p.u[k] = s->u[k]; p.v[k] = s->v[k]; p.w[k] = s->w[k];
-        p.amb[k] = s->ambient[k]; p.bg[k] = s->background[k];
-    }
-    p.left = s->left; p.right = s->right; p.top = s->top; p.bottom = s->bottom;
-    // viewport::to_struct (gfxraytrace.hpp:736-740) stores the resolution as floats.
-    p.xres_f = (float)s->xres; p.yres_f = (float)s->yres;
-    p.focal = s->focal;
+    for (int k = 0; k < 3; ++k) { p.amb[k] = s->ambient[k]; p.bg[k] = s->background[k]; }
     p.ka = s->ka; p.kd = s->kd; p.ks = s->ks;
     p.shader = s->shader;
-    p.xres = s->xres; p.yres = s->yres;
     p.n_sph = s->n_spheres; p.n_tri = s->n_tris;
-    p.n_tri_padded = (uint32_t)(filt.size() / 3);
-    p.n_sph_padded = (uint32_t)sfilt.size();
-    p.sph_filter = (const float4*)ctx->d_sph_filter;
-    p.tri_circle = (const float4*)ctx->d_tri_circle;
     p.n_lights = s->n_lights;
-    p.tri_filter = (const float4*)ctx->d_tri_filter;
     p.tri_exact = (const float4*)ctx->d_tri_exact;
     p.sph = (const float4*)ctx->d_sph;
     p.sph_mat = (const uint32_t*)ctx->d_sph_mat;
     p.mats = (const float4*)ctx->d_mats;
     p.lights = (const float4*)ctx->d_lights;
-    ctx->projection = s->projection;
+
+    if ((rc = rebuild_view(ctx)) != MRT_OK) return rc;     // synchronises the stream
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->upload_ms = ms;
+    ctx->have_scene = true;
+    return MRT_OK;
+}
+
+int mrt_set_camera(mrt_ctx* ctx, const mrt_camera* cam) {
+    if (!ctx) return MRT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
+    if (!cam) return fail(ctx, MRT_ERR_INVALID, "camera is NULL");
+    if (cam->xres == 0 || cam->yres == 0) return fail(ctx, MRT_ERR_INVALID, "resolution must be positive");
+    if (cam->xres > 65536u || cam->yres > 65536u) return fail(ctx, MRT_ERR_TOO_LARGE, "resolution above 65536");
+    if (cam->projection != MRT_PROJ_ORTHO && cam->projection != MRT_PROJ_PERSP)
+        return fail(ctx, MRT_ERR_INVALID, "unknown projection");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // Frames already enqueued on any stream still read the old records.
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    mrt_scene& h = ctx->h_scene;
+    for (int k = 0; k < 3; ++k) { h.eye[k] = cam->eye[k]; h.u[k] = cam->u[k]; h.v[k] = cam->v[k]; h.w[k] = cam->w[k]; }
+    h.xres = cam->xres; h.yres = cam->yres;
+    h.left = cam->left; h.right = cam->right; h.top = cam->top; h.bottom = cam->bottom;
+    h.projection = cam->projection;
+    h.focal = cam->focal;
+    ctx->have_scene = false;
+    int rc = rebuild_view(ctx);
+    if (rc != MRT_OK) return rc;
     ctx->have_scene = true;
     return MRT_OK;
 }
