@@ -114,7 +114,7 @@ class Job:
         nbytes = max(mrt.band_rows(st.yres, BAND_ROWS, r, world) for r in range(world)) * st.xres * 4
         self.local = [torch.empty(nbytes, dtype=torch.uint8, device=env.dev) for _ in range(2)]
         self.gathered = [([torch.empty(nbytes, dtype=torch.uint8, device=env.gdev) for _ in range(world)]
-                          if (world > 1 and env.rank == 0) else None) for _ in range(2)]
+                          if (env.use_dist and env.rank == 0) else None) for _ in range(2)]
         self.works = [None, None]
 
     def step(self, k):
@@ -124,7 +124,7 @@ class Job:
             self.works[b] = None
         self.ctx.render_bands_device(BAND_ROWS, env.rank, env.world, self.local[b].data_ptr(),
                                      self.local[b].numel(), stream=env.stream.cuda_stream)
-        if env.world > 1:
+        if env.use_dist:
             if env.rehearsal:
                 env.dist.gather(self.local[b].cpu(), self.gathered[b], dst=0)
             else:
@@ -138,7 +138,7 @@ class Job:
                 self.works[b].wait()
                 self.works[b] = None
         torch.cuda.synchronize(env.dev)
-        if env.world > 1:
+        if env.use_dist:
             env.dist.barrier()
         torch.cuda.synchronize(env.dev)
 
@@ -154,7 +154,7 @@ class Job:
             self.step(k)
         self.fence()
         elapsed = time.perf_counter() - t0
-        if env.world > 1:
+        if env.use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=env.gdev)
             env.dist.all_reduce(tt, op=env.dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -267,8 +267,12 @@ def main():
     env.dev = torch.device("cuda", env.dev_index)
     env.gdev = torch.device("cpu") if env.rehearsal else env.dev
     env.stream = torch.cuda.current_stream(env.dev)
-    if env.world > 1:
+    # MRT_BENCH_FORCE_DIST=1 runs the process-group code (RCCL gather, barrier, max-reduce) even
+    # with a single rank, to exercise it on a one-GPU box.
+    env.use_dist = env.world > 1 or os.environ.get("MRT_BENCH_FORCE_DIST") == "1"
+    if env.use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if env.rehearsal:
             dist.init_process_group("gloo", rank=env.rank, world_size=env.world)
         else:
@@ -300,7 +304,7 @@ def main():
             "config": {"workload": "teatime_4k" if world == 1 else f"teatime_3840x{st.yres}_bands{BAND_ROWS}",
                        "xres": st.xres, "yres": st.yres, "rays_per_step": total_rays,
                        "primitives": n_prims, "band_rows": BAND_ROWS,
-                       "gather": ("none" if world == 1 else
+                       "gather": ("none" if not env.use_dist else
                                   "REHEARSAL: all ranks on GPU 0, gloo gather through host memory"
                                   if env.rehearsal else "rccl gather to rank 0, overlapped with the next frame"),
                        "output": "RGBA8 resident in HBM (no D2H in the timed region)"},
@@ -328,7 +332,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sc)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if env.use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
