@@ -209,10 +209,14 @@ def secondary_workloads(env, mkscene):
         sc4k = mrt.LoadedScene(text=mkscene.teatime(XRES, YRES)).copy()
         for label, flags, steps in (("teatime_4k_edge_test_only_no_circle", mrt.FLAG_NO_CIRCLE, 5),
                                     ("teatime_4k_exact_test_only_no_prefilter", mrt.FLAG_NO_PREFILTER, 2),
-                                    ("teatime_4k_opt_in_block_reject", mrt.FLAG_BLOCK_REJECT, 5)):
+                                    ("teatime_4k_opt_in_block_reject", mrt.FLAG_BLOCK_REJECT, 5),
+                                    ("teatime_4k_opt_in_screen_cull", mrt.FLAG_SCREEN_CULL, 5)):
             job = Job(env, sc4k, flags=flags)
             frame_stats(job, label, steps=steps, warmup=1)
             job.close()
+        job = Job(env, mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy(), flags=mrt.FLAG_SCREEN_CULL)
+        frame_stats(job, "soup16k_opt_in_screen_cull", steps=3, warmup=1)
+        job.close()
     return res
 
 

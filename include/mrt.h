@@ -107,7 +107,12 @@ enum {
     MRT_FLAG_BLOCK_REJECT = 1u << 2,
     /* Skip the per-pixel bounding-circle test that precedes the per-pixel
      * edge-function test of a triangle (measurement aid; same pixels out). */
-    MRT_FLAG_NO_CIRCLE = 1u << 3
+    MRT_FLAG_NO_CIRCLE = 1u << 3,
+    /* Opt-in screen-space culling, off by default: per 32x32 wave tile the
+     * lanes first test 64 primitives each against the whole tile and only the
+     * survivors are tested per block, per pixel and exactly.  Same pixels out.
+     * This is an acceleration, not the brute-force path the benchmark grades. */
+    MRT_FLAG_SCREEN_CULL = 1u << 4
 };
 
 typedef struct mrt_stats {

@@ -21,6 +21,8 @@ namespace mrt {
 template <int PROJ, bool BLOCK_REJECT>
 __global__ void trace_kernel(const RenderParams p, float* t_out, int32_t* id_out, uint32_t pitch);
 template <int PROJ>
+__global__ void cull_trace_kernel(const RenderParams p, float* t_out, int32_t* id_out, uint32_t pitch);
+template <int PROJ>
 __global__ void shade_kernel(const RenderParams p, const float* t_in, const int32_t* id_in, uint32_t pitch);
 }  // namespace mrt
 
@@ -491,7 +493,15 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     const bool block = (ctx->flags & MRT_FLAG_BLOCK_REJECT) && (band_rows % 4 == 0);
     const bool persp = ctx->projection == MRT_PROJ_PERSP;
     const dim3 tb(mrt::kBlockThreads);
-    if (persp && block)
+    // The tile cull needs a wave tile's 32 rows to be consecutive image rows, and it has no
+    // exact-only mode of its own.
+    const bool cull = (ctx->flags & MRT_FLAG_SCREEN_CULL) && !(ctx->flags & MRT_FLAG_NO_PREFILTER) &&
+                      (band_rows % mrt::kWaveTile == 0);
+    if (cull && persp)
+        hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_PERSP>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+    else if (cull)
+        hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_ORTHO>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+    else if (persp && block)
         hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
     else if (persp)
         hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);

@@ -353,6 +353,145 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     }
 }
 
+// ---------------------------------------------------------------------------
+// Opt-in screen-space culling (MRT_FLAG_SCREEN_CULL); never the default path.
+//
+// Same tiles, same records, same exact pass as trace_kernel, but the first
+// rejection is done per wave tile with the lanes spread over PRIMITIVES: lane l
+// tests primitive base+l against the wave's whole 32x32 tile (nearest point of
+// the tile to the bounding circle / ellipse, and each edge function at its best
+// tile corner), a ballot gives the survivors, and only those are then tested
+// per 4x4 lane block, per pixel and exactly, in increasing object order.
+// Needs a tile's 32 rows to be consecutive image rows (band height a multiple
+// of 32); the host falls back to trace_kernel otherwise.
+// ---------------------------------------------------------------------------
+template <int PROJ>
+__global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderParams p,
+                                                                  float* __restrict__ t_out,
+                                                                  int32_t* __restrict__ id_out,
+                                                                  uint32_t pitch) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t wave_x0 = blockIdx.x * kBlockTileX + (wave & 1) * kWaveTile;
+    const uint32_t wave_lr0 = blockIdx.y * kBlockTileY + (wave >> 1) * kWaveTile;
+    if (!((wave_x0 < p.xres) && (wave_lr0 < p.local_rows))) return;   // no barriers in this kernel
+    const uint32_t x0 = wave_x0 + (lane & 7) * kLanePx;
+    const uint32_t lr0 = wave_lr0 + (lane >> 3) * kLanePx;
+
+    // Tile and lane-block origins in image pixel coordinates.
+    const float txf = (float)wave_x0;
+    const float tyf = (float)image_row(p, wave_lr0);
+    const float xf = (float)x0;
+    const float yf0 = tyf + (float)((lane >> 3) * kLanePx);
+    const float tile_span = (float)(kWaveTile - 1);
+
+#pragma unroll
+    for (int j = 0; j < kLanePx; ++j) {
+        const size_t off = (size_t)(lr0 + j) * pitch + x0;
+        *reinterpret_cast<float4*>(t_out + off) = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX);
+        *reinterpret_cast<int4*>(id_out + off) = make_int4(-1, -1, -1, -1);
+    }
+    unsigned long long n_exact = 0;
+
+    // ---- spheres ----
+    for (uint32_t base = 0; base < p.n_sph; base += 64) {
+        const float4 e = p.sph_filter[base + lane];          // padded to a multiple of 768
+        // (x*sx + ox) is monotone in x: nearest-to-zero value over the tile's columns.
+        const float du_lo = __builtin_fmaf(txf, e.x, e.y), dv_lo = __builtin_fmaf(tyf, e.z, e.w);
+        const float du = __builtin_amdgcn_fmed3f(du_lo, __builtin_fmaf(tile_span, e.x, du_lo), 0.0f);
+        const float dv = __builtin_amdgcn_fmed3f(dv_lo, __builtin_fmaf(tile_span, e.z, dv_lo), 0.0f);
+        // 1e-6: the per-pixel evaluation below rounds differently from this one.
+        const bool pass = (__builtin_fmaf(du, du, dv * dv) <= 1.000001f) && (base + lane < p.n_sph);
+        unsigned long long live = __builtin_amdgcn_ballot_w64(pass);
+        while (live) {
+            const uint32_t si = base + (uint32_t)__builtin_ctzll(live);
+            live &= live - 1;
+            const float4 f = p.sph_filter[si];
+            uint32_t mask = 0;
+            float dup = __builtin_fmaf(xf, f.x, f.y);
+#pragma unroll
+            for (int i = 0; i < kLanePx; ++i) {
+#pragma unroll
+                for (int j = 0; j < kLanePx; ++j) {
+                    const float dvp = __builtin_fmaf(yf0 + (float)j, f.z, f.w);
+                    if (__builtin_fmaf(dup, dup, __builtin_fmaf(dvp, dvp, -1.0f)) <= 0.0f) mask |= 1u << (j * kLanePx + i);
+                }
+                dup += f.x;
+            }
+            exact_pass<PROJ, false>(p, mask, si, x0, lr0, t_out, id_out, pitch, n_exact);
+        }
+    }
+
+    // ---- triangles ----
+    for (uint32_t base = 0; base < p.n_tri; base += 64) {
+        const uint32_t mine = base + lane;                    // records are padded to a multiple of 256
+        const float4 c = p.tri_circle[mine];
+        const float cu = __builtin_amdgcn_fmed3f(txf - c.x, txf + tile_span - c.x, 0.0f);
+        const float cv = __builtin_amdgcn_fmed3f(tyf - c.y, tyf + tile_span - c.y, 0.0f);
+        bool pass = __builtin_fmaf(cu, cu, __builtin_fmaf(cv, cv, -c.z)) <= 0.0f;
+        if (pass) {
+            // each edge function at the tile corner where it is largest
+            const float4 q0 = p.tri_filter[(size_t)mine * 3 + 0];
+            const float4 q1 = p.tri_filter[(size_t)mine * 3 + 1];
+            const float4 q2 = p.tri_filter[(size_t)mine * 3 + 2];
+            const float a[3] = {q0.x, q0.w, q1.z}, b[3] = {q0.y, q1.x, q1.w}, cc[3] = {q0.z, q1.y, q2.x};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float best_x = a[k] > 0.0f ? txf + tile_span : txf;
+                const float best_y = b[k] > 0.0f ? tyf + tile_span : tyf;
+                // slack 1e-3 px for the different rounding of the per-pixel evaluation
+                pass = pass && (__builtin_fmaf(a[k], best_x, __builtin_fmaf(b[k], best_y, cc[k])) >= -1e-3f);
+            }
+        }
+        unsigned long long live = __builtin_amdgcn_ballot_w64(pass && mine < p.n_tri);
+        while (live) {
+            const uint32_t ti = base + (uint32_t)__builtin_ctzll(live);
+            live &= live - 1;
+            const float4 q0 = p.tri_filter[(size_t)ti * 3 + 0];
+            const float4 q1 = p.tri_filter[(size_t)ti * 3 + 1];
+            const float4 q2 = p.tri_filter[(size_t)ti * 3 + 2];
+            const float a0 = q0.x, b0 = q0.y, a1 = q0.w, b1 = q1.x, a2 = q1.z, b2 = q1.w;
+            // 4x4 block reject: best corner of this lane's block, via C'_k (see push_record)
+            const float m0 = __builtin_fmaf(a0, xf, __builtin_fmaf(b0, yf0, q2.y));
+            const float m1 = __builtin_fmaf(a1, xf, __builtin_fmaf(b1, yf0, q2.z));
+            const float m2 = __builtin_fmaf(a2, xf, __builtin_fmaf(b2, yf0, q2.w));
+            const bool blk = __builtin_fminf(__builtin_fminf(m0, m1), m2) >= 0.0f;
+            if (__builtin_amdgcn_ballot_w64(blk) == 0) continue;
+            const float c0 = __builtin_fmaf(a0, xf, q0.z);
+            const float c1 = __builtin_fmaf(a1, xf, q1.y);
+            const float c2 = __builtin_fmaf(a2, xf, q2.x);
+            uint32_t mask = 0;
+#pragma unroll
+            for (int j = 0; j < kLanePx; ++j) {
+                const float y = yf0 + (float)j;
+                float v0 = __builtin_fmaf(b0, y, c0);
+                float v1 = __builtin_fmaf(b1, y, c1);
+                float v2 = __builtin_fmaf(b2, y, c2);
+#pragma unroll
+                for (int i = 0; i < kLanePx; ++i) {
+                    if (__builtin_fminf(__builtin_fminf(v0, v1), v2) >= 0.0f) mask |= 1u << (j * kLanePx + i);
+                    v0 += a0; v1 += a1; v2 += a2;
+                }
+            }
+            exact_pass<PROJ, true>(p, mask, ti, x0, lr0, t_out, id_out, pitch, n_exact);
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < kLanePx; ++j) {
+        const size_t off = (size_t)(lr0 + j) * pitch + x0;
+        float4 tv = *reinterpret_cast<const float4*>(t_out + off);
+        const int4 iv = *reinterpret_cast<const int4*>(id_out + off);
+        tv.x = iv.x < 0 ? -1.0f : tv.x;
+        tv.y = iv.y < 0 ? -1.0f : tv.y;
+        tv.z = iv.z < 0 ? -1.0f : tv.z;
+        tv.w = iv.w < 0 ? -1.0f : tv.w;
+        *reinterpret_cast<float4*>(t_out + off) = tv;
+    }
+    if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
+}
+
 // One thread per pixel; consecutive lanes take consecutive pixels of a row so
 // each wave writes 256 contiguous bytes of RGBA8.
 template <int PROJ>
@@ -430,6 +569,8 @@ template __global__ void trace_kernel<MRT_PROJ_ORTHO, false>(const RenderParams,
 template __global__ void trace_kernel<MRT_PROJ_PERSP, false>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_ORTHO, true>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_PERSP, true>(const RenderParams, float*, int32_t*, uint32_t);
+template __global__ void cull_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, float*, int32_t*, uint32_t);
+template __global__ void cull_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void shade_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float*, const int32_t*, uint32_t);
 template __global__ void shade_kernel<MRT_PROJ_PERSP>(const RenderParams, const float*, const int32_t*, uint32_t);
 

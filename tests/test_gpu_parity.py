@@ -111,6 +111,7 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
     a = mrt.Context(device=0, flags=mrt.FLAG_COUNT_EXACT)
     b = mrt.Context(device=0, flags=mrt.FLAG_BLOCK_REJECT | mrt.FLAG_COUNT_EXACT)
     c = mrt.Context(device=0, flags=mrt.FLAG_NO_CIRCLE | mrt.FLAG_COUNT_EXACT)
+    d = mrt.Context(device=0, flags=mrt.FLAG_SCREEN_CULL | mrt.FLAG_COUNT_EXACT)
     try:
         rng = np.random.default_rng(5)
         cases = [scene_py.load_scene(SCENES / "teatime.json", xres=1280, yres=720,
@@ -129,6 +130,10 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
             assert_same_hits(ra, rc)
             assert np.array_equal(ra["rgba"], rc["rgba"])
             assert rc["stats"].exact_tests == ra["stats"].exact_tests
+            rd = gpu_render(d, sc)                                        # opt-in tile culling
+            assert_same_hits(ra, rd)
+            assert np.array_equal(ra["rgba"], rd["rgba"])
+            assert rd["stats"].exact_tests <= ra["stats"].exact_tests * 1.01 + 64
         # bands of 6 rows: the block path must step aside (a lane's rows are not consecutive)
         sc = cases[0]
         b.set_scene(sc)
@@ -140,10 +145,21 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
             b.render_bands_device(6, r, 2, g[r].data_ptr(), stride)
         torch.cuda.synchronize()
         assert np.array_equal(mrt.bands_to_image(g.cpu().numpy(), stride, 1280, 720, 6, 2), full)
+        # the tile cull needs 32 consecutive rows: bands of 32 use it, bands of 6 fall back
+        d.set_scene(sc)
+        for band in (32, 6):
+            rows = [mrt.band_rows(720, band, r, 3) for r in range(3)]
+            stride = max(rows) * 1280 * 4
+            g = torch.zeros((3, stride), dtype=torch.uint8, device="cuda:0")
+            for r in range(3):
+                d.render_bands_device(band, r, 3, g[r].data_ptr(), stride)
+            torch.cuda.synchronize()
+            assert np.array_equal(mrt.bands_to_image(g.cpu().numpy(), stride, 1280, 720, band, 3), full)
     finally:
         a.close()
         b.close()
         c.close()
+        d.close()
 
 
 def test_degenerate_and_edge_on_triangles(gpu_ctx, mrt, oracle):

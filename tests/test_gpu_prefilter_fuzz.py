@@ -89,6 +89,7 @@ def _scene(mrt, rng, kind, proj):
 def test_prefilters_never_drop_an_exact_hit(mrt, kind):
     fast = mrt.Context(device=0)
     blk = mrt.Context(device=0, flags=mrt.FLAG_BLOCK_REJECT)
+    cull = mrt.Context(device=0, flags=mrt.FLAG_SCREEN_CULL)
     exact = mrt.Context(device=0, flags=mrt.FLAG_NO_PREFILTER)
     rng = np.random.default_rng(zlib.crc32(kind.encode()))
     try:
@@ -98,7 +99,7 @@ def test_prefilters_never_drop_an_exact_hit(mrt, kind):
             sc = _scene(mrt, rng, kind, proj)
             exact.set_scene(sc)
             _, ids_e, t_e, _ = exact.render(want_ids=True)
-            for ctx in (fast, blk):
+            for ctx in (fast, blk, cull):
                 ctx.set_scene(sc)
                 _, ids_f, t_f, _ = ctx.render(want_ids=True)
                 bad = int((ids_f != ids_e).sum())
@@ -109,4 +110,5 @@ def test_prefilters_never_drop_an_exact_hit(mrt, kind):
     finally:
         fast.close()
         blk.close()
+        cull.close()
         exact.close()
