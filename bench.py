@@ -94,6 +94,27 @@ def profiled_traffic():
     return None, None
 
 
+def profiled_valu_issue():
+    """VALU issue utilisation of trace_kernel from the same committed counter passes: wave
+    instructions per SIMD (256 CUs x 4) over the launch's GPU cycles (GRBM_GUI_ACTIVE is summed
+    over the 8 XCDs), against the cycles this instruction mix needs at the issue rates measured
+    with tools/valu_bench.hip (2 cycles for full-rate ops, 4 for min/max, mix average 2.33)."""
+    for f in sorted((ROOT / "profiles").glob("r*/teatime4k_pmc_summary.json"), reverse=True):
+        try:
+            for name, entry in json.loads(f.read_text()).items():
+                if "trace_kernel" in name:
+                    c = entry["counters_mean_per_launch"]
+                    cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+                    per_inst = cycles / (c["SQ_INSTS_VALU"] / 1024.0)
+                    return {"insts_valu_per_launch": c["SQ_INSTS_VALU"], "gpu_cycles_per_launch": cycles,
+                            "cycles_per_inst_per_simd": per_inst, "ideal_cycles_per_inst": 2.33,
+                            "util": 2.33 / per_inst, "lds_bank_conflicts": c.get("SQ_LDS_BANK_CONFLICT"),
+                            "source": str(f.relative_to(ROOT))}
+        except (KeyError, ValueError, ZeroDivisionError):
+            continue
+    return None
+
+
 class Env:
     """Process-wide state: rank, devices, the loaded package."""
 
@@ -209,6 +230,7 @@ def secondary_workloads(env, mkscene):
         sc4k = mrt.LoadedScene(text=mkscene.teatime(XRES, YRES)).copy()
         for label, flags, steps in (("teatime_4k_edge_test_only_no_circle", mrt.FLAG_NO_CIRCLE, 5),
                                     ("teatime_4k_exact_test_only_no_prefilter", mrt.FLAG_NO_PREFILTER, 2),
+                                    ("teatime_4k_full_test_every_pair", mrt.FLAG_FULL_TEST, 3),
                                     ("teatime_4k_opt_in_block_reject", mrt.FLAG_BLOCK_REJECT, 5),
                                     ("teatime_4k_opt_in_screen_cull", mrt.FLAG_SCREEN_CULL, 5)):
             job = Job(env, sc4k, flags=flags)
@@ -318,6 +340,7 @@ def main():
                 "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel_ms": trace_avg, "shade_kernel_ms": shade_avg, "flops_per_launch": flops_launch,
+                "valu_issue": profiled_valu_issue() if world == 1 else None,
                 "note": "algorithmic FLOPs: 45 per ray-triangle test, 20 per ray-sphere test, every ray x "
                         "every primitive; the kernel rejects most pairs per pixel with a one-FMA bounding-circle "
                         "test, so executed FLOPs are far lower and frac exceeds 1; VALU issue utilisation from "

@@ -112,7 +112,14 @@ enum {
      * lanes first test 64 primitives each against the whole tile and only the
      * survivors are tested per block, per pixel and exactly.  Same pixels out.
      * This is an acceleration, not the brute-force path the benchmark grades. */
-    MRT_FLAG_SCREEN_CULL = 1u << 4
+    MRT_FLAG_SCREEN_CULL = 1u << 4,
+    /* No rejection in screen space at all: every (pixel, object) pair
+     * evaluates the determinants of tri_intersect / the discriminant of
+     * circle_intersect (kernel.cl:197-303) with the reference's own operation
+     * order; only the divisions and the square root wait until the numerators
+     * cannot already fail a range test.  Same pixels out.  Takes precedence
+     * over the other flags. */
+    MRT_FLAG_FULL_TEST = 1u << 5
 };
 
 typedef struct mrt_stats {

@@ -21,6 +21,7 @@ FLAG_COUNT_EXACT = 1 << 1
 FLAG_BLOCK_REJECT = 1 << 2
 FLAG_NO_CIRCLE = 1 << 3
 FLAG_SCREEN_CULL = 1 << 4
+FLAG_FULL_TEST = 1 << 5
 PROJ_ORTHO, PROJ_PERSP = 0, 1
 SHADER_FLAT, SHADER_PHONG = 0, 1
 

@@ -23,6 +23,11 @@ __global__ void trace_kernel(const RenderParams p, float* t_out, int32_t* id_out
 template <int PROJ>
 __global__ void cull_trace_kernel(const RenderParams p, float* t_out, int32_t* id_out, uint32_t pitch);
 template <int PROJ>
+__global__ void full_trace_kernel(const RenderParams p, const float4* full_rec, float* t_out, int32_t* id_out,
+                                  uint32_t pitch);
+template <int PROJ>
+__global__ void prep_full_records(const RenderParams p, float4* rec);
+template <int PROJ>
 __global__ void shade_kernel(const RenderParams p, const float* t_in, const int32_t* id_in, uint32_t pitch);
 }  // namespace mrt
 
@@ -51,6 +56,8 @@ struct mrt_ctx {
     void* d_tri_circle = nullptr;
     size_t cap_sph_filter = 0, cap_tri_filter = 0, cap_tri_circle = 0;
     void* d_tri_exact = nullptr;
+    void* d_full_rec = nullptr;     // MRT_FLAG_FULL_TEST only: per-view records of full_trace_kernel
+    size_t cap_full_rec = 0;
     void* d_sph = nullptr;
     void* d_sph_mat = nullptr;
     void* d_mats = nullptr;
@@ -487,6 +494,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     if (p.exact_counter) HIP_TRY(ctx, hipMemsetAsync(p.exact_counter, 0, sizeof(unsigned long long), stream));
 
     const dim3 tgrid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY);
+    const dim3 fgrid(pitch / mrt::kBlockTileX, prow / 32);      // full_trace_kernel: blocks of 64 x 32 pixels
     const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
     // The block reject needs a lane's four rows to be consecutive image rows.
@@ -497,7 +505,13 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     // exact-only mode of its own.
     const bool cull = (ctx->flags & MRT_FLAG_SCREEN_CULL) && !(ctx->flags & MRT_FLAG_NO_PREFILTER) &&
                       (band_rows % mrt::kWaveTile == 0);
-    if (cull && persp)
+    if ((ctx->flags & MRT_FLAG_FULL_TEST) && persp)
+        hipLaunchKernelGGL((mrt::full_trace_kernel<MRT_PROJ_PERSP>), fgrid, tb, 0, stream, p,
+                           (const float4*)ctx->d_full_rec, ctx->d_t, ctx->d_id, pitch);
+    else if (ctx->flags & MRT_FLAG_FULL_TEST)
+        hipLaunchKernelGGL((mrt::full_trace_kernel<MRT_PROJ_ORTHO>), fgrid, tb, 0, stream, p,
+                           (const float4*)ctx->d_full_rec, ctx->d_t, ctx->d_id, pitch);
+    else if (cull && persp)
         hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_PERSP>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
     else if (cull)
         hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_ORTHO>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
@@ -585,7 +599,7 @@ void mrt_destroy(mrt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    free_dev(ctx->d_sph_filter); free_dev(ctx->d_tri_filter); free_dev(ctx->d_tri_circle); free_dev(ctx->d_tri_exact); free_dev(ctx->d_sph);
+    free_dev(ctx->d_sph_filter); free_dev(ctx->d_tri_filter); free_dev(ctx->d_tri_circle); free_dev(ctx->d_tri_exact); free_dev(ctx->d_full_rec); free_dev(ctx->d_sph);
     free_dev(ctx->d_sph_mat); free_dev(ctx->d_mats); free_dev(ctx->d_lights);
     if (ctx->d_t) (void)hipFree(ctx->d_t);
     if (ctx->d_id) (void)hipFree(ctx->d_id);
@@ -624,6 +638,28 @@ static int rebuild_view(mrt_ctx* ctx) {
     p.tri_filter = (const float4*)ctx->d_tri_filter;
     p.tri_circle = (const float4*)ctx->d_tri_circle;
     ctx->projection = s->projection;
+
+    if (ctx->flags & MRT_FLAG_FULL_TEST) {
+        // Records of full_trace_kernel, made on the device so that they carry the device's own
+        // roundings; padded with zeros to whole LDS chunks (the kernel never tests the padding).
+        const size_t bytes = (size_t)round_up(s->n_tris ? s->n_tris : 1, mrt::kChunkTris) * 3 * sizeof(float4);
+        if (!ctx->d_full_rec || ctx->cap_full_rec != bytes) {
+            free_dev(ctx->d_full_rec);
+            ctx->cap_full_rec = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->d_full_rec, bytes));
+            ctx->cap_full_rec = bytes;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_full_rec, 0, bytes, ctx->stream));
+        if (s->n_tris) {
+            const dim3 g((s->n_tris + 255) / 256), b(256);
+            if (s->projection == MRT_PROJ_PERSP)
+                hipLaunchKernelGGL(mrt::prep_full_records<MRT_PROJ_PERSP>, g, b, 0, ctx->stream, p, (float4*)ctx->d_full_rec);
+            else
+                hipLaunchKernelGGL(mrt::prep_full_records<MRT_PROJ_ORTHO>, g, b, 0, ctx->stream, p, (float4*)ctx->d_full_rec);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return MRT_OK;
 }
 

@@ -492,6 +492,259 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
     if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
 }
 
+// ---------------------------------------------------------------------------
+// MRT_FLAG_FULL_TEST: the reference's determinants for EVERY (pixel, primitive)
+// pair -- no screen-space rejection of any kind.
+//
+// tri_intersect (kernel.cl:197-235) solves by Cramer's rule: four 3x3
+// determinants det, Nb, Ng, Nt, then beta = Nb/det, gamma = Ng/det, t = Nt/det
+// and the range tests.  This kernel evaluates the four determinants for every
+// pair with the reference's own operation order (so they are the reference's
+// values bit for bit; the 2x2 minors det and Nb share are computed once, and
+// for the pinhole camera Nt does not depend on the pixel and comes with the
+// record) and postpones only the three divisions: a pair is dropped when the
+// SIGNS and magnitudes of the numerators already decide a range test,
+//     min(Nb', Ng', Nt') < 0            beta < 0, gamma < 0 or t < 0
+//     Nb' + Ng' > |det| (1 + 1e-5)      beta > 1 - gamma (covers gamma > 1)
+//     Nt'       > |det| bound (1 + 1e-5) t above the closest hit so far
+// (N' = N * sign(det)), each with enough slack that the correctly rounded
+// quotient fails the same test; everything else takes the divisions through
+// tri_exact.  Spheres: the discriminant of circle_intersect (kernel.cl:248-254)
+// for every pair; sqrt and division only where it is not negative.
+//
+// A lane owns 4x2 pixels, a wave 32x16, a block 64x32; the closest hit stays
+// in registers.  Records (3 x float4 per triangle, made by prep_full_records)
+// are staged through LDS in the same 12 KiB chunks as the prefilter records.
+// ---------------------------------------------------------------------------
+constexpr int kFullPxX = 4, kFullPxY = 2, kFullSlots = kFullPxX * kFullPxY;
+constexpr int kFullWaveH = 8 * kFullPxY;          // 16 rows per wave
+constexpr int kFullBlockH = 2 * kFullWaveH;       // 32 rows per block
+
+namespace {
+
+struct M3 { float m0, m1, m2; };
+// The three 2x2 minors determinant3x3 (kernel.cl:149-155) forms from its second
+// and third argument, and its expansion along the first: det3(a, b, c) ==
+// expand(a, minors(b, c)) operation for operation.
+__device__ __forceinline__ M3 minors(F3 b, F3 c) {
+    M3 r;
+    r.m0 = b.y * c.z - b.z * c.y;
+    r.m1 = b.x * c.z - b.z * c.x;
+    r.m2 = b.x * c.y - b.y * c.x;
+    return r;
+}
+__device__ __forceinline__ float expand(F3 a, M3 m) {
+    float det = a.x * m.m0;
+    det -= a.y * m.m1;
+    det += a.z * m.m2;
+    return det;
+}
+
+// >= 0 when the pair (numerators Nb, Ng, Nt over det, closest hit so far below
+// bound_up = bound * (1 + 1e-5)) may still be accepted by tri_intersect and the
+// closest-hit loop; < 0 only when one of their tests certainly fails.
+__device__ __forceinline__ float tri_candidate(float det, float nb, float ng, float nt, float bound_up) {
+    const float sg = __builtin_copysignf(1.0f, det);
+    const float b = nb * sg, g = ng * sg, t = nt * sg;       // exact
+    const float ad = __builtin_fabsf(det);
+    const float c1 = __builtin_fminf(__builtin_fminf(b, g), t);
+    const float q2 = __builtin_fmaf(ad, 1.00001f, -(b + g));
+    const float q3 = __builtin_fmaf(bound_up, ad, -t);
+    // + |det| 2^-100: a negative numerator only counts when the quotient cannot round to -0
+    return __builtin_fmaf(ad, 0x1p-100f, __builtin_fminf(__builtin_fminf(c1, q2), q3));
+}
+
+}  // namespace
+
+// Per-view triangle records of full_trace_kernel, by the same arithmetic as
+// tri_intersect: pinhole (s1 | s2 | a - eye | Nt), orthographic (s1 | s2 | a |
+// minors(s2, d)) with s1 = a - b, s2 = a - c (kernel.cl:204-206).
+template <int PROJ>
+__global__ void prep_full_records(const RenderParams p, float4* __restrict__ rec) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.n_tri) return;
+    const float4 va = p.tri_exact[(size_t)k * 3 + 0];
+    const float4 vb = p.tri_exact[(size_t)k * 3 + 1];
+    const float4 vc = p.tri_exact[(size_t)k * 3 + 2];
+    const F3 a = mk3(va.x, va.y, va.z);
+    const F3 s1 = sub3(a, mk3(vb.x, vb.y, vb.z));
+    const F3 s2 = sub3(a, mk3(vc.x, vc.y, vc.z));
+    if (PROJ == MRT_PROJ_PERSP) {
+        const F3 sol = sub3(a, mk3(p.eye[0], p.eye[1], p.eye[2]));
+        const float nt = det3(s1, s2, sol);
+        rec[(size_t)k * 3 + 0] = make_float4(s1.x, s1.y, s1.z, s2.x);
+        rec[(size_t)k * 3 + 1] = make_float4(s2.y, s2.z, sol.x, sol.y);
+        rec[(size_t)k * 3 + 2] = make_float4(sol.z, nt, 0.0f, 0.0f);
+    } else {
+        const M3 m = minors(s2, mk3(-p.w[0], -p.w[1], -p.w[2]));
+        rec[(size_t)k * 3 + 0] = make_float4(s1.x, s1.y, s1.z, s2.x);
+        rec[(size_t)k * 3 + 1] = make_float4(s2.y, s2.z, a.x, a.y);
+        rec[(size_t)k * 3 + 2] = make_float4(a.z, m.m0, m.m1, m.m2);
+    }
+}
+
+template <int PROJ>
+__global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderParams p,
+                                                                  const float4* __restrict__ full_rec,
+                                                                  float* __restrict__ t_out,
+                                                                  int32_t* __restrict__ id_out, uint32_t pitch) {
+    __shared__ float4 s_rec[kChunkFloat4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t wave_x0 = blockIdx.x * kBlockTileX + (wave & 1) * kWaveTile;
+    const uint32_t wave_lr0 = blockIdx.y * kFullBlockH + (wave >> 1) * kFullWaveH;
+    const bool wave_active = (wave_x0 < p.xres) && (wave_lr0 < p.local_rows);
+    const uint32_t x0 = wave_x0 + (lane & 7) * kFullPxX;
+    const uint32_t lr0 = wave_lr0 + (lane >> 3) * kFullPxY;
+
+    // Per pixel: the part of the primary ray that depends on it (direction for the
+    // pinhole camera, origin for the orthographic one) and the closest hit so far.
+    F3 ray[kFullSlots];
+    float best_t[kFullSlots], bound_up[kFullSlots];
+    int32_t best_id[kFullSlots];
+    F3 shared_part = mk3(0.f, 0.f, 0.f);   // the other half of the ray, the same for every pixel
+    {
+        const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
+#pragma unroll
+        for (int j = 0; j < kFullPxY; ++j) {
+            const uint32_t lr = lr0 + j;
+            const uint32_t y = image_row(p, lr < last_row ? lr : last_row);
+            const float uy = uv_component(p.bottom, p.top, (float)y + 1.0f, p.yres_f);
+#pragma unroll
+            for (int i = 0; i < kFullPxX; ++i) {
+                const float ux = uv_component(p.left, p.right, (float)(x0 + i) + 1.0f, p.xres_f);
+                F3 o, d;
+                pixel_ray<PROJ>(p, ux, uy, o, d);
+                ray[j * kFullPxX + i] = (PROJ == MRT_PROJ_PERSP) ? d : o;
+                shared_part = (PROJ == MRT_PROJ_PERSP) ? o : d;
+                best_t[j * kFullPxX + i] = FLT_MAX;               // gfxraytrace.hpp:813
+                bound_up[j * kFullPxX + i] = __builtin_inff();
+                best_id[j * kFullPxX + i] = -1;
+            }
+        }
+    }
+
+    // ---- spheres: object ids 0 .. n_sph-1 ----
+    for (uint32_t base = 0; base < p.n_sph; base += kChunkFloat4) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kChunkFloat4 / kBlockThreads; ++k) {
+            const uint32_t idx = base + tid + k * kBlockThreads;
+            s_rec[tid + k * kBlockThreads] = idx < p.n_sph ? p.sph[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+        const uint32_t count = (p.n_sph - base) < (uint32_t)kChunkFloat4 ? (p.n_sph - base) : (uint32_t)kChunkFloat4;
+        for (uint32_t g = 0; g < count; ++g) {
+            const float4 sp = s_rec[g];
+            const F3 center = mk3(sp.x, sp.y, sp.z);
+            float acc = -1.0f;
+#pragma unroll
+            for (int s = 0; s < kFullSlots; ++s) {
+                const F3 o = (PROJ == MRT_PROJ_PERSP) ? shared_part : ray[s];
+                const F3 d = (PROJ == MRT_PROJ_PERSP) ? ray[s] : shared_part;
+                float a, b;
+                acc = __builtin_fmaxf(acc, sphere_disc(center, sp.w, o, d, a, b));   // < 0: miss, kernel.cl:256
+            }
+            if (__builtin_amdgcn_ballot_w64(acc >= 0.0f) == 0) continue;
+            if (acc >= 0.0f) {
+#pragma unroll
+                for (int s = 0; s < kFullSlots; ++s) {
+                    const F3 o = (PROJ == MRT_PROJ_PERSP) ? shared_part : ray[s];
+                    const F3 d = (PROJ == MRT_PROJ_PERSP) ? ray[s] : shared_part;
+                    float t;
+                    bool two;
+                    if (sphere_exact(center, sp.w, o, d, best_t[s], 0.0f, t, two) && t > 0.0f && t < best_t[s]) {
+                        best_t[s] = t;
+                        bound_up[s] = t * 1.00001f;
+                        best_id[s] = (int32_t)(base + g);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- triangles: object ids n_sph .. n_sph+n_tri-1 ----
+    for (uint32_t base = 0; base < p.n_tri; base += kChunkTris) {
+        __syncthreads();
+        stage_chunk(s_rec, full_rec + (size_t)base * 3, tid);     // padded to whole chunks
+        __syncthreads();
+        if (!wave_active) continue;
+        const uint32_t count = (p.n_tri - base) < (uint32_t)kChunkTris ? (p.n_tri - base) : (uint32_t)kChunkTris;
+        for (uint32_t g = 0; g < count; ++g) {
+            const float4 q0 = s_rec[g * 3 + 0];
+            const float4 q1 = s_rec[g * 3 + 1];
+            const float4 q2 = s_rec[g * 3 + 2];
+            const F3 s1 = mk3(q0.x, q0.y, q0.z);
+            const F3 s2 = mk3(q0.w, q1.x, q1.y);
+            const F3 third = mk3(q1.z, q1.w, q2.x);     // a - eye (pinhole) or a (orthographic)
+            float acc = -1.0f;
+            if (PROJ == MRT_PROJ_PERSP) {
+                const float nt = q2.y;
+#pragma unroll
+                for (int s = 0; s < kFullSlots; ++s) {
+                    const M3 m = minors(s2, ray[s]);
+                    const float det = expand(s1, m);
+                    const float nb = expand(third, m);
+                    const float ng = expand(s1, minors(third, ray[s]));
+                    acc = __builtin_fmaxf(acc, tri_candidate(det, nb, ng, nt, bound_up[s]));
+                }
+            } else {
+                M3 m;
+                m.m0 = q2.y; m.m1 = q2.z; m.m2 = q2.w;
+                const float det = expand(s1, m);
+#pragma unroll
+                for (int s = 0; s < kFullSlots; ++s) {
+                    const F3 sol = sub3(third, ray[s]);
+                    const float nb = expand(sol, m);
+                    const float ng = expand(s1, minors(sol, shared_part));
+                    const float nt = expand(s1, minors(s2, sol));
+                    acc = __builtin_fmaxf(acc, tri_candidate(det, nb, ng, nt, bound_up[s]));
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(acc >= 0.0f) == 0) continue;
+            if (acc >= 0.0f) {
+                const uint32_t ti = base + g;
+                const float4 va = p.tri_exact[(size_t)ti * 3 + 0];
+                const float4 vb = p.tri_exact[(size_t)ti * 3 + 1];
+                const float4 vc = p.tri_exact[(size_t)ti * 3 + 2];
+                const F3 A = mk3(va.x, va.y, va.z), B = mk3(vb.x, vb.y, vb.z), C = mk3(vc.x, vc.y, vc.z);
+#pragma unroll
+                for (int s = 0; s < kFullSlots; ++s) {
+                    const F3 o = (PROJ == MRT_PROJ_PERSP) ? shared_part : ray[s];
+                    const F3 d = (PROJ == MRT_PROJ_PERSP) ? ray[s] : shared_part;
+                    float t;
+                    if (tri_exact(A, B, C, o, d, best_t[s], 0.0f, t) && t > 0.0f && t < best_t[s]) {
+                        best_t[s] = t;
+                        bound_up[s] = t * 1.00001f;
+                        best_id[s] = (int32_t)(p.n_sph + ti);
+                    }
+                }
+            }
+        }
+    }
+
+    if (wave_active) {
+#pragma unroll
+        for (int j = 0; j < kFullPxY; ++j) {
+            const size_t off = (size_t)(lr0 + j) * pitch + x0;
+            float4 tv;
+            int4 iv;
+            iv.x = best_id[j * 4 + 0]; iv.y = best_id[j * 4 + 1]; iv.z = best_id[j * 4 + 2]; iv.w = best_id[j * 4 + 3];
+            tv.x = iv.x < 0 ? -1.0f : best_t[j * 4 + 0];          // intersect.t_ of a miss, kernel.cl:363
+            tv.y = iv.y < 0 ? -1.0f : best_t[j * 4 + 1];
+            tv.z = iv.z < 0 ? -1.0f : best_t[j * 4 + 2];
+            tv.w = iv.w < 0 ? -1.0f : best_t[j * 4 + 3];
+            *reinterpret_cast<float4*>(t_out + off) = tv;
+            *reinterpret_cast<int4*>(id_out + off) = iv;
+        }
+        if (p.exact_counter != nullptr)
+            atomicAdd(p.exact_counter, (unsigned long long)kFullSlots * ((unsigned long long)p.n_sph + p.n_tri));
+    }
+}
+
 // One thread per pixel; consecutive lanes take consecutive pixels of a row so
 // each wave writes 256 contiguous bytes of RGBA8.
 template <int PROJ>
@@ -569,6 +822,10 @@ template __global__ void trace_kernel<MRT_PROJ_ORTHO, false>(const RenderParams,
 template __global__ void trace_kernel<MRT_PROJ_PERSP, false>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_ORTHO, true>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_PERSP, true>(const RenderParams, float*, int32_t*, uint32_t);
+template __global__ void full_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float4*, float*, int32_t*, uint32_t);
+template __global__ void full_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, const float4*, float*, int32_t*, uint32_t);
+template __global__ void prep_full_records<MRT_PROJ_ORTHO>(const RenderParams, float4*);
+template __global__ void prep_full_records<MRT_PROJ_PERSP>(const RenderParams, float4*);
 template __global__ void cull_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void cull_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void shade_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float*, const int32_t*, uint32_t);

@@ -112,6 +112,7 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
     b = mrt.Context(device=0, flags=mrt.FLAG_BLOCK_REJECT | mrt.FLAG_COUNT_EXACT)
     c = mrt.Context(device=0, flags=mrt.FLAG_NO_CIRCLE | mrt.FLAG_COUNT_EXACT)
     d = mrt.Context(device=0, flags=mrt.FLAG_SCREEN_CULL | mrt.FLAG_COUNT_EXACT)
+    e = mrt.Context(device=0, flags=mrt.FLAG_FULL_TEST | mrt.FLAG_COUNT_EXACT)
     try:
         rng = np.random.default_rng(5)
         cases = [scene_py.load_scene(SCENES / "teatime.json", xres=1280, yres=720,
@@ -134,6 +135,10 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
             assert_same_hits(ra, rd)
             assert np.array_equal(ra["rgba"], rd["rgba"])
             assert rd["stats"].exact_tests <= ra["stats"].exact_tests * 1.01 + 64
+            re_ = gpu_render(e, sc)                                       # determinants for every pair
+            assert_same_hits(ra, re_)
+            assert np.array_equal(ra["rgba"], re_["rgba"])
+            assert re_["stats"].exact_tests >= sc.struct.xres * sc.struct.yres * sc.n_objects
         # bands of 6 rows: the block path must step aside (a lane's rows are not consecutive)
         sc = cases[0]
         b.set_scene(sc)
@@ -155,11 +160,20 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
                 d.render_bands_device(band, r, 3, g[r].data_ptr(), stride)
             torch.cuda.synchronize()
             assert np.array_equal(mrt.bands_to_image(g.cpu().numpy(), stride, 1280, 720, band, 3), full)
+        e.set_scene(sc)
+        rows = [mrt.band_rows(720, 6, r, 2) for r in range(2)]
+        stride = max(rows) * 1280 * 4
+        g = torch.zeros((2, stride), dtype=torch.uint8, device="cuda:0")
+        for r in range(2):
+            e.render_bands_device(6, r, 2, g[r].data_ptr(), stride)
+        torch.cuda.synchronize()
+        assert np.array_equal(mrt.bands_to_image(g.cpu().numpy(), stride, 1280, 720, 6, 2), full)
     finally:
         a.close()
         b.close()
         c.close()
         d.close()
+        e.close()
 
 
 def test_degenerate_and_edge_on_triangles(gpu_ctx, mrt, oracle):

@@ -90,6 +90,7 @@ def test_prefilters_never_drop_an_exact_hit(mrt, kind):
     fast = mrt.Context(device=0)
     blk = mrt.Context(device=0, flags=mrt.FLAG_BLOCK_REJECT)
     cull = mrt.Context(device=0, flags=mrt.FLAG_SCREEN_CULL)
+    full = mrt.Context(device=0, flags=mrt.FLAG_FULL_TEST)
     exact = mrt.Context(device=0, flags=mrt.FLAG_NO_PREFILTER)
     rng = np.random.default_rng(zlib.crc32(kind.encode()))
     try:
@@ -99,7 +100,7 @@ def test_prefilters_never_drop_an_exact_hit(mrt, kind):
             sc = _scene(mrt, rng, kind, proj)
             exact.set_scene(sc)
             _, ids_e, t_e, _ = exact.render(want_ids=True)
-            for ctx in (fast, blk, cull):
+            for ctx in (fast, blk, cull, full):
                 ctx.set_scene(sc)
                 _, ids_f, t_f, _ = ctx.render(want_ids=True)
                 bad = int((ids_f != ids_e).sum())
@@ -111,4 +112,5 @@ def test_prefilters_never_drop_an_exact_hit(mrt, kind):
         fast.close()
         blk.close()
         cull.close()
+        full.close()
         exact.close()
