@@ -202,10 +202,10 @@ def secondary_workloads(env, mkscene):
     mrt = env.mrt
     res = {}
 
-    def frame_stats(job, name, steps, warmup, extra=None):
+    def frame_stats(job, name, steps, warmup, extra=None, kernel_reps=3):
         st = job.st
         elapsed = job.timed(steps, warmup)
-        tr, sh = job.kernel_ms(3)
+        tr, sh = job.kernel_ms(kernel_reps)
         rays = st.xres * st.yres
         n_prims = st.n_spheres + st.n_tris
         e = {"xres": st.xres, "yres": st.yres, "n_gpus": env.world, "primitives": n_prims,
@@ -230,14 +230,17 @@ def secondary_workloads(env, mkscene):
         sc4k = mrt.LoadedScene(text=mkscene.teatime(XRES, YRES)).copy()
         for label, flags, steps in (("teatime_4k_edge_test_only_no_circle", mrt.FLAG_NO_CIRCLE, 5),
                                     ("teatime_4k_exact_test_only_no_prefilter", mrt.FLAG_NO_PREFILTER, 2),
-                                    ("teatime_4k_full_test_every_pair", mrt.FLAG_FULL_TEST, 3),
                                     ("teatime_4k_opt_in_block_reject", mrt.FLAG_BLOCK_REJECT, 5),
                                     ("teatime_4k_opt_in_screen_cull", mrt.FLAG_SCREEN_CULL, 5)):
             job = Job(env, sc4k, flags=flags)
             frame_stats(job, label, steps=steps, warmup=1)
             job.close()
-        job = Job(env, mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy(), flags=mrt.FLAG_SCREEN_CULL)
+        soup = mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy()
+        job = Job(env, soup, flags=mrt.FLAG_SCREEN_CULL)
         frame_stats(job, "soup16k_opt_in_screen_cull", steps=3, warmup=1)
+        job.close()
+        job = Job(env, soup, flags=mrt.FLAG_FULL_TEST)          # 4.7e12 pairs, about 3 s per frame
+        frame_stats(job, "soup16k_full_test_every_pair", steps=1, warmup=0, kernel_reps=1)
         job.close()
     return res
 
@@ -350,6 +353,20 @@ def main():
         if world == 1:
             out["host_frame"] = host_frame(env, job, total_rays)
     job.close()
+    if world == 1:
+        # The same frame with MRT_FLAG_FULL_TEST: no rejection in screen space, every pair evaluates
+        # the reference's four determinants (33 unfused multiplies/adds) -- the row of the roofline
+        # whose executed arithmetic is the priced arithmetic.
+        fjob = Job(env, sc, flags=mrt.FLAG_FULL_TEST)
+        fjob.timed(1, 1)
+        f_trace, _ = fjob.kernel_ms(3)
+        fjob.close()
+        f_ach = flops_launch / (f_trace * 1e-3) * 1e-12
+        out["roofline"]["full_test_kernel"] = {
+            "kernel": "full_trace_kernel", "kernel_ms": f_trace, "mrays_per_s": total_rays / f_trace * 1e-3,
+            "achieved": f_ach, "frac": f_ach / FP32_PEAK_TFLOPS,
+            "note": "MRT_FLAG_FULL_TEST: determinants of tri_intersect for every (pixel, triangle) pair in the "
+                    "reference's operation order, divisions deferred; same pixels as the default path"}
     if not args.no_secondary:
         sec = secondary_workloads(env, mkscene)
         if rank == 0:

@@ -540,18 +540,30 @@ __device__ __forceinline__ float expand(F3 a, M3 m) {
     return det;
 }
 
+// A constant held in a vector register.  VALU instructions that read a scalar
+// register or a literal issue at half rate on this chip, so the constants of
+// the inner loop are made opaque to the compiler once, outside it.
+__device__ __forceinline__ float in_vgpr(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
+
+struct CandConst { float one, rel_up, tiny; uint32_t absmask; };   // 1.0, 1 + 1e-5, 2^-100, 0x7fffffff
+
 // >= 0 when the pair (numerators Nb, Ng, Nt over det, closest hit so far below
 // bound_up = bound * (1 + 1e-5)) may still be accepted by tri_intersect and the
 // closest-hit loop; < 0 only when one of their tests certainly fails.
-__device__ __forceinline__ float tri_candidate(float det, float nb, float ng, float nt, float bound_up) {
-    const float sg = __builtin_copysignf(1.0f, det);
+__device__ __forceinline__ float tri_candidate(float det, float nb, float ng, float nt, float bound_up,
+                                               const CandConst& k) {
+    // copysign(1, det) with the mask in a vector register
+    const float sg = __uint_as_float((__float_as_uint(k.one) & k.absmask) | (__float_as_uint(det) & ~k.absmask));
     const float b = nb * sg, g = ng * sg, t = nt * sg;       // exact
     const float ad = __builtin_fabsf(det);
     const float c1 = __builtin_fminf(__builtin_fminf(b, g), t);
-    const float q2 = __builtin_fmaf(ad, 1.00001f, -(b + g));
+    const float q2 = __builtin_fmaf(ad, k.rel_up, -(b + g));
     const float q3 = __builtin_fmaf(bound_up, ad, -t);
     // + |det| 2^-100: a negative numerator only counts when the quotient cannot round to -0
-    return __builtin_fmaf(ad, 0x1p-100f, __builtin_fminf(__builtin_fminf(c1, q2), q3));
+    return __builtin_fmaf(ad, k.tiny, __builtin_fminf(__builtin_fminf(c1, q2), q3));
 }
 
 }  // namespace
@@ -626,6 +638,11 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
         }
     }
 
+    shared_part = mk3(in_vgpr(shared_part.x), in_vgpr(shared_part.y), in_vgpr(shared_part.z));
+    CandConst kc;
+    kc.one = in_vgpr(1.0f); kc.rel_up = in_vgpr(1.00001f); kc.tiny = in_vgpr(0x1p-100f);
+    kc.absmask = __float_as_uint(in_vgpr(__uint_as_float(0x7fffffffu)));
+
     // ---- spheres: object ids 0 .. n_sph-1 ----
     for (uint32_t base = 0; base < p.n_sph; base += kChunkFloat4) {
         __syncthreads();
@@ -689,7 +706,7 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                     const float det = expand(s1, m);
                     const float nb = expand(third, m);
                     const float ng = expand(s1, minors(third, ray[s]));
-                    acc = __builtin_fmaxf(acc, tri_candidate(det, nb, ng, nt, bound_up[s]));
+                    acc = __builtin_fmaxf(acc, tri_candidate(det, nb, ng, nt, bound_up[s], kc));
                 }
             } else {
                 M3 m;
@@ -701,7 +718,7 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                     const float nb = expand(sol, m);
                     const float ng = expand(s1, minors(sol, shared_part));
                     const float nt = expand(s1, minors(s2, sol));
-                    acc = __builtin_fmaxf(acc, tri_candidate(det, nb, ng, nt, bound_up[s]));
+                    acc = __builtin_fmaxf(acc, tri_candidate(det, nb, ng, nt, bound_up[s], kc));
                 }
             }
             if (__builtin_amdgcn_ballot_w64(acc >= 0.0f) == 0) continue;

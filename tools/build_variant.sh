@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/opencl-raytracing_amd/csrc
 OUT=$ROOT/variants/$NAME
 mkdir -p "$OUT"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$ROOT/include -I$SRC $*"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -I$ROOT/include -I$SRC $*"
 for f in mrt_kernels mrt_host mrt_stages; do /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OUT/$f.o; done
 for f in scene_loader json_min png_writer; do g++ -O2 -std=c++17 -fPIC -I$ROOT/include -I$SRC -c $SRC/$f.cpp -o $OUT/$f.o; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libmrt_hip.so $OUT/*.o -lz -lpthread

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Kernel time of one scene under a list of mrt_config flag sets (GPU box only).
+
+usage: time_flags.py [teatime|soup] XRES YRES FLAGS [FLAGS ...]     (FLAGS are integers)
+"""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
+import torch  # noqa: E402,F401  (one HIP runtime for the process)
+import mrt_pkg  # noqa: E402
+import mkscene  # noqa: E402
+
+mrt = mrt_pkg.load()
+kind, xres, yres = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+text = mkscene.teatime(xres, yres) if kind == "teatime" else mkscene.soup(xres, yres)
+scene = mrt.LoadedScene(text=text).copy()
+out = torch.empty(xres * yres, dtype=torch.int32, device="cuda:0")
+for flags in (int(a, 0) for a in sys.argv[4:]):
+    ctx = mrt.Context(device=0, flags=flags)
+    ctx.set_scene(scene)
+    best = None
+    for _ in range(4):
+        st = ctx.render_bands_device(64, 0, 1, out.data_ptr(), out.numel() * 4, timed=True)
+        best = st.trace_ms if best is None else min(best, st.trace_ms)
+    print(f"flags={flags:#x} trace_ms={best:.3f} mrays_per_s={xres * yres / best * 1e-3:.1f}", flush=True)
+    ctx.close()
