@@ -86,7 +86,7 @@ def profiled_traffic():
     try:
         data = json.loads(best.read_text())
         for name, entry in data.items():
-            if "trace_kernel" in name:
+            if "mrt::trace_kernel" in name:
                 c = entry["counters_mean_per_launch"]
                 return c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024, str(best.relative_to(ROOT))
     except (KeyError, ValueError):
@@ -94,21 +94,22 @@ def profiled_traffic():
     return None, None
 
 
-def profiled_valu_issue():
-    """VALU issue utilisation of trace_kernel from the same committed counter passes: wave
+def profiled_valu_issue(kernel="mrt::trace_kernel", ideal=2.33):
+    """VALU issue utilisation of one kernel from the same committed counter passes: wave
     instructions per SIMD (256 CUs x 4) over the launch's GPU cycles (GRBM_GUI_ACTIVE is summed
-    over the 8 XCDs), against the cycles this instruction mix needs at the issue rates measured
-    with tools/valu_bench.hip (2 cycles for full-rate ops, 4 for min/max, mix average 2.33)."""
+    over the 8 XCDs), against the cycles its instruction mix needs at the issue rates measured
+    with tools/valu_bench.hip (2 cycles for full-rate ops, 3.3 for three-source ops, 4 for
+    two-source min/max: 2.33 on average for trace_kernel, 2.12 for full_trace_kernel)."""
     for f in sorted((ROOT / "profiles").glob("r*/teatime4k_pmc_summary.json"), reverse=True):
         try:
             for name, entry in json.loads(f.read_text()).items():
-                if "trace_kernel" in name:
+                if kernel in name:
                     c = entry["counters_mean_per_launch"]
                     cycles = c["GRBM_GUI_ACTIVE"] / 8.0
                     per_inst = cycles / (c["SQ_INSTS_VALU"] / 1024.0)
                     return {"insts_valu_per_launch": c["SQ_INSTS_VALU"], "gpu_cycles_per_launch": cycles,
-                            "cycles_per_inst_per_simd": per_inst, "ideal_cycles_per_inst": 2.33,
-                            "util": 2.33 / per_inst, "lds_bank_conflicts": c.get("SQ_LDS_BANK_CONFLICT"),
+                            "cycles_per_inst_per_simd": per_inst, "ideal_cycles_per_inst": ideal,
+                            "util": ideal / per_inst, "lds_bank_conflicts": c.get("SQ_LDS_BANK_CONFLICT"),
                             "source": str(f.relative_to(ROOT))}
         except (KeyError, ValueError, ZeroDivisionError):
             continue
@@ -365,6 +366,7 @@ def main():
         out["roofline"]["full_test_kernel"] = {
             "kernel": "full_trace_kernel", "kernel_ms": f_trace, "mrays_per_s": total_rays / f_trace * 1e-3,
             "achieved": f_ach, "frac": f_ach / FP32_PEAK_TFLOPS,
+            "valu_issue": profiled_valu_issue("mrt::full_trace_kernel", 2.12),
             "note": "MRT_FLAG_FULL_TEST: determinants of tri_intersect for every (pixel, triangle) pair in the "
                     "reference's operation order, divisions deferred; same pixels as the default path"}
     if not args.no_secondary:

@@ -11,7 +11,7 @@
 //    by default.  Every hit/miss decision, t, location, normal and colour that
 //    reaches a pixel comes from these functions.
 //
-//  * the conservative triangle prefilter (in mrt_hip.hip) uses explicit
+//  * the conservative triangle prefilter (in mrt_kernels.hip) uses explicit
 //    __builtin_fmaf and only ever decides "this pixel cannot hit this
 //    triangle"; it never produces a value that is written out.
 #pragma once

@@ -30,6 +30,14 @@ namespace mrt {
 
 namespace {
 
+// A constant held in a vector register.  VALU instructions that read a scalar
+// register or a literal issue at half rate on this chip, so the constants of
+// the inner loop are made opaque to the compiler once, outside it.
+__device__ __forceinline__ float in_vgpr(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
+
 // Image row of packed local row lr for this rank (interleaved bands).
 __device__ __forceinline__ uint32_t image_row(const RenderParams& p, uint32_t lr) {
     uint32_t band = lr / p.band_rows;
@@ -538,14 +546,6 @@ __device__ __forceinline__ float expand(F3 a, M3 m) {
     det -= a.y * m.m1;
     det += a.z * m.m2;
     return det;
-}
-
-// A constant held in a vector register.  VALU instructions that read a scalar
-// register or a literal issue at half rate on this chip, so the constants of
-// the inner loop are made opaque to the compiler once, outside it.
-__device__ __forceinline__ float in_vgpr(float x) {
-    asm("" : "+v"(x));
-    return x;
 }
 
 struct CandConst { float one, rel_up, tiny; uint32_t absmask; };   // 1.0, 1 + 1e-5, 2^-100, 0x7fffffff

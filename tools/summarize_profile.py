@@ -40,7 +40,7 @@ def main(src, dst):
                 f.write(f"\"{k}\",{c},{v:.6g}\n")
     print((dst / "teatime4k_kernel_stats.csv").read_text())
     for k, d in out.items():
-        if "trace" in k:
+        if "trace_kernel" in k:
             print(k, d["dispatch"])
             for c, v in d["counters_mean_per_launch"].items():
                 print(f"  {c:28s} {v:.6g}")
