@@ -459,7 +459,9 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
             const float4 q0 = p.tri_filter[(size_t)ti * 3 + 0];
             const float4 q1 = p.tri_filter[(size_t)ti * 3 + 1];
             const float4 q2 = p.tri_filter[(size_t)ti * 3 + 2];
-            const float a0 = q0.x, b0 = q0.y, a1 = q0.w, b1 = q1.x, a2 = q1.z, b2 = q1.w;
+            // wave-uniform loads land in scalar registers; VALU operands read from those issue at half rate
+            const float a0 = in_vgpr(q0.x), b0 = in_vgpr(q0.y), a1 = in_vgpr(q0.w), b1 = in_vgpr(q1.x),
+                        a2 = in_vgpr(q1.z), b2 = in_vgpr(q1.w);
             // 4x4 block reject: best corner of this lane's block, via C'_k (see push_record)
             const float m0 = __builtin_fmaf(a0, xf, __builtin_fmaf(b0, yf0, q2.y));
             const float m1 = __builtin_fmaf(a1, xf, __builtin_fmaf(b1, yf0, q2.z));

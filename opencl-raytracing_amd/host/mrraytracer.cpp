@@ -86,6 +86,8 @@ int main(int argc, char** argv) {
     std::cout << "raytracing..." << std::flush;
     mrt_ctx* ctx = nullptr;
     mrt_config cfg = {-1, MRT_FLAG_NONE};
+    // MRT_FLAGS=<integer> selects one of the library's other kernels (mrt.h, mrt_flags); same pixels.
+    if (const char* f = std::getenv("MRT_FLAGS")) cfg.flags = static_cast<uint32_t>(std::strtoul(f, nullptr, 0));
     std::vector<uint8_t> pixels(static_cast<size_t>(scene->xres) * scene->yres * 4);
     mrt_stats stats;
     int rc = mrt_create(&cfg, &ctx);
