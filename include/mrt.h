@@ -176,6 +176,14 @@ int mrt_set_camera(mrt_ctx *ctx, const mrt_camera *camera);
  * (gfxraytrace.hpp:830-878) and the per-stage calls it makes. */
 int mrt_render_rgba8(mrt_ctx *ctx, uint8_t *host_out, mrt_stats *stats /* may be NULL */);
 
+/* Page-locked host memory for mrt_render_rgba8's host_out: the device-to-host
+ * copy then runs at PCIe rate instead of through the runtime's bounce buffers
+ * (about 3x at 3840x2160).  Any other host memory works too.  Takes the place
+ * of the `new rgbColor[count]` result arrays of the reference's stage helpers
+ * (CLHelpers.hpp:254,293), which the caller owns and never frees. */
+int mrt_host_alloc(size_t bytes, void **out);
+void mrt_host_free(void *p);
+
 /* As mrt_render_rgba8, additionally returning per pixel the winning object id
  * (-1 = miss) and its ray parameter t (-1.0f for a miss), the fields
  * intersect.t_ / intersects of CLStructs.hpp:115-128.  ids/t may be NULL. */

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "mrt_bands_to_image", "mrt_scene_load_file", "mrt_scene_load_text", "mrt_scene_view",
     "mrt_scene_info_view", "mrt_scene_free", "mrt_write_png_rgb", "mrt_stage_uv",
     "mrt_stage_ortho_viewrays", "mrt_stage_persp_viewrays", "mrt_stage_intersect",
-    "mrt_stage_flat_shader", "mrt_stage_phong_shader",
+    "mrt_stage_flat_shader", "mrt_stage_phong_shader", "mrt_host_alloc", "mrt_host_free",
 ]
 
 _fp = C.POINTER(C.c_float)
@@ -163,6 +163,9 @@ def lib():
     L.mrt_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
     L.mrt_render_rgba8.argtypes = [vp, vp, C.POINTER(Stats)]
     L.mrt_render_debug.argtypes = [vp, vp, vp, vp, C.POINTER(Stats)]
+    L.mrt_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.mrt_host_free.argtypes = [vp]
+    L.mrt_host_free.restype = None
     L.mrt_band_rows.argtypes = [C.c_uint32] * 4
     L.mrt_band_rows.restype = C.c_uint32
     L.mrt_render_bands_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp,
@@ -328,10 +331,13 @@ class Context:
         self._check(lib().mrt_set_camera(self._h, C.byref(cam)))
         self.xres, self.yres = st.xres, st.yres
 
-    def render(self, want_ids=False):
-        """Returns (rgba[y, x, 4] uint8, stats) or (rgba, ids, t, stats)."""
+    def render(self, want_ids=False, out=None):
+        """Returns (rgba[y, x, 4] uint8, stats) or (rgba, ids, t, stats).  out: an RGBA8 array to
+        render into (for example one from host_array(), which is page-locked)."""
         stats = Stats()
-        img = np.empty((self.yres, self.xres, 4), np.uint8)
+        img = np.empty((self.yres, self.xres, 4), np.uint8) if out is None else out
+        if img.shape != (self.yres, self.xres, 4) or img.dtype != np.uint8 or not img.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of shape (yres, xres, 4)")
         if not want_ids:
             self._check(lib().mrt_render_rgba8(self._h, img.ctypes.data, C.byref(stats)))
             return img, stats
@@ -396,6 +402,34 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class _PinnedBlock:
+    """Owns one mrt_host_alloc block."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        rc = lib().mrt_host_alloc(nbytes, C.byref(p))
+        if rc != 0:
+            raise MrtError(rc, "mrt_host_alloc failed")
+        self.ptr = p.value
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().mrt_host_free(self.ptr)
+            self.ptr = None
+
+
+def host_array(shape, dtype=np.uint8):
+    """A numpy array in page-locked host memory (mrt_host_alloc).  The block is freed when the
+    last array viewing it is gone: numpy holds the ctypes buffer, the buffer holds the block."""
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(count * dtype.itemsize, 1)
+    block = _PinnedBlock(nbytes)
+    buf = (C.c_uint8 * nbytes).from_address(block.ptr)
+    buf._owner = block
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
 
 def band_rows(yres, rows_per_band, rank, world):

@@ -841,6 +841,22 @@ int mrt_render_rgba8(mrt_ctx* ctx, uint8_t* host_out, mrt_stats* stats) {
     return mrt_render_debug(ctx, host_out, nullptr, nullptr, stats);
 }
 
+int mrt_host_alloc(size_t bytes, void** out) {
+    if (!out) return MRT_ERR_INVALID;
+    *out = nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, MRT_ERR_HIP, "hipHostMalloc failed");
+    }
+    *out = p;
+    return MRT_OK;
+}
+
+void mrt_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int mrt_bands_to_image(const uint8_t* gathered, size_t stride_bytes, uint32_t xres, uint32_t yres,
                        uint32_t band_rows, uint32_t world, uint8_t* image_out) {
     if (!gathered || !image_out || band_rows == 0 || world == 0 || xres == 0) return MRT_ERR_INVALID;

@@ -88,13 +88,17 @@ int main(int argc, char** argv) {
     mrt_config cfg = {-1, MRT_FLAG_NONE};
     // MRT_FLAGS=<integer> selects one of the library's other kernels (mrt.h, mrt_flags); same pixels.
     if (const char* f = std::getenv("MRT_FLAGS")) cfg.flags = static_cast<uint32_t>(std::strtoul(f, nullptr, 0));
-    std::vector<uint8_t> pixels(static_cast<size_t>(scene->xres) * scene->yres * 4);
+    const size_t n_bytes = static_cast<size_t>(scene->xres) * scene->yres * 4;
     mrt_stats stats;
+    void* pinned = nullptr;
     int rc = mrt_create(&cfg, &ctx);
+    if (rc == MRT_OK) rc = mrt_host_alloc(n_bytes, &pinned);
+    uint8_t* pixels = static_cast<uint8_t*>(pinned);
     if (rc == MRT_OK) rc = mrt_set_scene(ctx, scene);
-    if (rc == MRT_OK) rc = mrt_render_rgba8(ctx, pixels.data(), &stats);
+    if (rc == MRT_OK) rc = mrt_render_rgba8(ctx, pixels, &stats);
     if (rc != MRT_OK) {
         std::cerr << std::endl << "error: render failed: " << mrt_last_error(ctx) << std::endl;
+        mrt_host_free(pinned);
         mrt_destroy(ctx);
         mrt_scene_free(loaded);
         return 1;
@@ -102,8 +106,9 @@ int main(int argc, char** argv) {
     std::cout << "done" << std::endl;
 
     std::cout << "writing " << output_path << "..." << std::flush;
-    if (mrt_write_png_rgb(output_path.c_str(), pixels.data(), scene->xres, scene->yres) != MRT_OK) {
+    if (mrt_write_png_rgb(output_path.c_str(), pixels, scene->xres, scene->yres) != MRT_OK) {
         std::cerr << std::endl << "error: could not write PNG" << std::endl;
+        mrt_host_free(pinned);
         mrt_destroy(ctx);
         mrt_scene_free(loaded);
         return 1;
@@ -119,6 +124,7 @@ int main(int argc, char** argv) {
                      stats.trace_ms, stats.shade_ms, stats.download_ms,
                      stats.kernel_ms > 0 ? stats.rays / stats.kernel_ms * 1e-3 : 0.0);
     }
+    mrt_host_free(pinned);
     mrt_destroy(ctx);
     mrt_scene_free(loaded);
     return 0;

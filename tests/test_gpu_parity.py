@@ -319,6 +319,15 @@ def test_teatime_4k_full_frame_against_oracle(gpu_ctx, mrt, oracle):
     assert_same_hits(r, o)
     stats = check(r["rgba"], o["rgba"], o["ids"])
     assert stats["within_1lsb"] == stats["pixels"]
+    # the other kernels on the same frame: determinants for every pair, and the opt-in tile cull
+    for flags in (mrt.FLAG_FULL_TEST, mrt.FLAG_SCREEN_CULL, mrt.FLAG_BLOCK_REJECT):
+        ctx = mrt.Context(device=0, flags=flags)
+        try:
+            r2 = gpu_render(ctx, ls)
+        finally:
+            ctx.close()
+        assert_same_hits(r2, o)
+        assert np.array_equal(r2["rgba"], r["rgba"])
 
 
 def test_soup_all_primitives_against_oracle(gpu_ctx, mrt, oracle):
@@ -348,7 +357,17 @@ def test_soup_16k_rows_against_oracle(mrt, oracle):
         assert np.array_equal(ids[y], o["ids"][y])
         assert np.array_equal(t[y], o["t"][y])
         check(img[y:y + 1], o["rgba"][y:y + 1], o["ids"][y:y + 1])
-    del img, ids, t
+    # size-independent property at the full size: the tile-cull kernel must reproduce all
+    # 268 435 456 winners and t values of the default kernel
+    ctx = mrt.Context(device=0, flags=mrt.FLAG_SCREEN_CULL)
+    try:
+        ctx.set_scene(sc)
+        img2, ids2, t2, _ = ctx.render(want_ids=True)
+    finally:
+        ctx.close()
+    assert np.array_equal(ids2, ids) and np.array_equal(t2.view(np.uint32), t.view(np.uint32))
+    assert np.array_equal(img2, img)
+    del img, ids, t, img2, ids2, t2
 
 
 def test_set_camera_equals_fresh_scene(mrt, oracle):
@@ -386,6 +405,15 @@ def test_render_is_deterministic(gpu_ctx, mrt):
     a = gpu_render(gpu_ctx, ls)
     b = gpu_render(gpu_ctx, ls)
     assert np.array_equal(a["rgba"], b["rgba"]) and np.array_equal(a["ids"], b["ids"])
+    # into page-locked memory from mrt_host_alloc: same bytes; the block outlives the first view
+    pinned = mrt.host_array((720, 1280, 4))
+    img, _ = gpu_ctx.render(out=pinned)
+    assert img is pinned and np.array_equal(pinned, a["rgba"])
+    view = pinned[100:200]
+    del pinned, img
+    assert np.array_equal(view, a["rgba"][100:200])
+    with pytest.raises(ValueError):
+        gpu_ctx.render(out=np.empty((10, 10, 4), np.uint8))
 
 
 @pytest.mark.parametrize("world,band", [(2, 64), (3, 16), (8, 64), (4, 7)])
