@@ -2,6 +2,8 @@
 #include "json_min.hpp"
 
 #include <cerrno>
+#include <charconv>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -158,21 +160,31 @@ struct Reader {
             if (p >= end || *p < '0' || *p > '9') return fail("bad exponent");
             while (p < end && *p >= '0' && *p <= '9') ++p;
         }
-        std::string tok(s, p);
+        // The token is already validated; from_chars converts it in place, correctly rounded.
         if (!is_float) {
-            errno = 0;
-            char* e = nullptr;
             if (neg) {
-                long long x = std::strtoll(tok.c_str(), &e, 10);
-                if (errno == 0 && e && *e == 0) { v.kind = Kind::Int; v.i = x; return true; }
+                long long x = 0;
+                auto r = std::from_chars(s, p, x);
+                if (r.ec == std::errc() && r.ptr == p) { v.kind = Kind::Int; v.i = x; return true; }
             } else {
-                unsigned long long x = std::strtoull(tok.c_str(), &e, 10);
-                if (errno == 0 && e && *e == 0) { v.kind = Kind::UInt; v.u = x; return true; }
+                unsigned long long x = 0;
+                auto r = std::from_chars(s, p, x);
+                if (r.ec == std::errc() && r.ptr == p) { v.kind = Kind::UInt; v.u = x; return true; }
             }
             // Out of 64-bit range: the token becomes a float.
         }
         v.kind = Kind::Float;
-        v.d = std::strtod(tok.c_str(), nullptr);
+        double x = 0.0;
+        auto r = std::from_chars(s, p, x);
+        if (r.ec == std::errc::result_out_of_range) {
+            // strtod semantics: +-HUGE_VAL on overflow, a zero or denormal on underflow
+            std::string tok(s, p);
+            x = std::strtod(tok.c_str(), nullptr);
+        }
+        // The DOM library the reference uses refuses a literal that overflows double
+        // ("number overflow parsing"), so it is a parse error here too.
+        if (!std::isfinite(x)) { p = s; return fail("number overflow"); }
+        v.d = x;
         return true;
     }
     bool value(Value& v) {
@@ -197,6 +209,7 @@ struct Reader {
         ++p;
         skip_ws();
         if (p < end && *p == ']') { ++p; return true; }
+        v.items.reserve(4);
         while (true) {
             v.items.emplace_back();
             if (!value(v.items.back())) return false;
@@ -212,6 +225,7 @@ struct Reader {
         ++p;
         skip_ws();
         if (p < end && *p == '}') { ++p; return true; }
+        v.members.reserve(8);
         while (true) {
             skip_ws();
             std::string key;

@@ -163,6 +163,18 @@ def test_loader_misc(mrt):
     assert mrt.LoadedScene(text=text).struct.xres == 77
     # trailing text after the first JSON value is not an error (stream extraction)
     assert mrt.LoadedScene(text=mutate() + "\n\ntrailing").struct.xres == 40
+    # number tokens: exponents, underflow to zero, integers beyond 64 bits become floats,
+    # a float literal beyond double is a parse error
+    base = mutate()
+    assert '"viewport_right": 1.0' in base
+    ok = mrt.LoadedScene(text=base.replace('"viewport_right": 1.0', '"viewport_right": 0.1E+1'))
+    assert ok.struct.right == 1.0
+    tiny = mrt.LoadedScene(text=base.replace("[0, 0, 0]", "[1e-400, -0.0, 2.5e-1]", 1))
+    assert tiny.struct.xres == 40
+    assert load_err(mrt, base.replace('"viewport_right": 1.0', '"viewport_right": 1e999')) == \
+        'JSON parse error reading "<memory>"'
+    assert load_err(mrt, base.replace('"x_resolution": 40', '"x_resolution": 123456789012345678901234567890')) == \
+        'key "x_resolution" must be an integer'
 
 
 def test_band_partition_helpers(mrt):
