@@ -99,7 +99,7 @@ def profiled_valu_issue(kernel="mrt::trace_kernel", ideal=2.33):
     instructions per SIMD (256 CUs x 4) over the launch's GPU cycles (GRBM_GUI_ACTIVE is summed
     over the 8 XCDs), against the cycles its instruction mix needs at the issue rates measured
     with tools/valu_bench.hip (2 cycles for full-rate ops, 3.3 for three-source ops, 4 for
-    two-source min/max: 2.33 on average for trace_kernel, 2.12 for full_trace_kernel)."""
+    two-source min/max: 2.33 on average for trace_kernel, 2.09 for full_trace_kernel)."""
     for f in sorted((ROOT / "profiles").glob("r*/teatime4k_pmc_summary.json"), reverse=True):
         try:
             for name, entry in json.loads(f.read_text()).items():
@@ -371,7 +371,7 @@ def main():
         out["roofline"]["full_test_kernel"] = {
             "kernel": "full_trace_kernel", "kernel_ms": f_trace, "mrays_per_s": total_rays / f_trace * 1e-3,
             "achieved": f_ach, "frac": f_ach / FP32_PEAK_TFLOPS,
-            "valu_issue": profiled_valu_issue("mrt::full_trace_kernel", 2.12),
+            "valu_issue": profiled_valu_issue("mrt::full_trace_kernel", 2.09),
             "note": "MRT_FLAG_FULL_TEST: determinants of tri_intersect for every (pixel, triangle) pair in the "
                     "reference's operation order, divisions deferred; same pixels as the default path"}
     if not args.no_secondary:

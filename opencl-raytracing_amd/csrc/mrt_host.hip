@@ -631,6 +631,20 @@ static int rebuild_view(mrt_ctx* ctx) {
     // viewport::to_struct (gfxraytrace.hpp:736-740) stores the resolution as floats.
     p.xres_f = (float)s->xres; p.yres_f = (float)s->yres;
     p.focal = s->focal;
+    {
+        // Largest |component| a primary-ray direction can have (persp_viewrays, kernel.cl:140-147:
+        // -w f + u uv.x + v uv.y; the orthographic direction is -w), with room for rounding.
+        auto amax = [](const float* a) { return std::fmax(std::fabs((double)a[0]), std::fmax(std::fabs((double)a[1]), std::fabs((double)a[2]))); };
+        // uv of the last pixel lies half a pixel beyond the viewport edge (kernel.cl:126-127)
+        const double mux = std::fmax(std::fabs((double)s->left), std::fabs((double)s->right)) +
+                           std::fabs((double)s->right - (double)s->left) / s->xres;
+        const double muy = std::fmax(std::fabs((double)s->top), std::fabs((double)s->bottom)) +
+                           std::fabs((double)s->top - (double)s->bottom) / s->yres;
+        const double dmax = s->projection == MRT_PROJ_PERSP
+                                ? std::fabs((double)s->focal) * amax(s->w) + mux * amax(s->u) + muy * amax(s->v)
+                                : amax(s->w);
+        p.ray_absmax = (float)(dmax * 1.01);
+    }
     p.xres = s->xres; p.yres = s->yres;
     p.n_tri_padded = (uint32_t)(filt.size() / 3);
     p.n_sph_padded = (uint32_t)sfilt.size();

@@ -512,15 +512,19 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
 // pair with the reference's own operation order (so they are the reference's
 // values bit for bit; the 2x2 minors det and Nb share are computed once, and
 // for the pinhole camera Nt does not depend on the pixel and comes with the
-// record) and postpones only the three divisions: a pair is dropped when the
-// SIGNS and magnitudes of the numerators already decide a range test,
-//     min(Nb', Ng', Nt') < 0            beta < 0, gamma < 0 or t < 0
-//     Nb' + Ng' > |det| (1 + 1e-5)      beta > 1 - gamma (covers gamma > 1)
-//     Nt'       > |det| bound (1 + 1e-5) t above the closest hit so far
-// (N' = N * sign(det)), each with enough slack that the correctly rounded
-// quotient fails the same test; everything else takes the divisions through
-// tri_exact.  Spheres: the discriminant of circle_intersect (kernel.cl:248-254)
-// for every pair; sqrt and division only where it is not negative.
+// record) and postpones only the three divisions.  A hit needs t = Nt/det > 0,
+// so the sign s of det at a hit is known per triangle (the sign of Nt for the
+// pinhole camera, of det itself for the orthographic one) and a pair is dropped
+// when signs and magnitudes of the numerators already decide a range test:
+//     s Nb < 0 or s Ng < 0               beta < 0 or gamma < 0
+//     s (Nb + Ng) > s det (1 + 1e-5)     beta > 1 - gamma (covers gamma > 1)
+//     s Nt > s det bound (1 + 1e-5)      t above the closest hit so far, or t < 0
+// each with enough slack that the correctly rounded quotient fails the same
+// test, and with a band of 2^-100 max|det| around zero so that a quotient that
+// would round to -0 (which the reference's "< 0" lets through) is never
+// dropped.  Everything else takes the divisions through tri_exact.  Spheres:
+// the discriminant of circle_intersect (kernel.cl:248-254) for every pair; sqrt
+// and division only where it is not negative.
 //
 // A lane owns 4x2 pixels, a wave 32x16, a block 64x32; the closest hit stays
 // in registers.  Records (3 x float4 per triangle, made by prep_full_records)
@@ -550,22 +554,20 @@ __device__ __forceinline__ float expand(F3 a, M3 m) {
     return det;
 }
 
-struct CandConst { float one, rel_up, tiny; uint32_t absmask; };   // 1.0, 1 + 1e-5, 2^-100, 0x7fffffff
-
-// >= 0 when the pair (numerators Nb, Ng, Nt over det, closest hit so far below
-// bound_up = bound * (1 + 1e-5)) may still be accepted by tri_intersect and the
-// closest-hit loop; < 0 only when one of their tests certainly fails.
-__device__ __forceinline__ float tri_candidate(float det, float nb, float ng, float nt, float bound_up,
-                                               const CandConst& k) {
-    // copysign(1, det) with the mask in a vector register
-    const float sg = __uint_as_float((__float_as_uint(k.one) & k.absmask) | (__float_as_uint(det) & ~k.absmask));
-    const float b = nb * sg, g = ng * sg, t = nt * sg;       // exact
-    const float ad = __builtin_fabsf(det);
-    const float c1 = __builtin_fminf(__builtin_fminf(b, g), t);
-    const float q2 = __builtin_fmaf(ad, k.rel_up, -(b + g));
-    const float q3 = __builtin_fmaf(bound_up, ad, -t);
-    // + |det| 2^-100: a negative numerator only counts when the quotient cannot round to -0
-    return __builtin_fmaf(ad, k.tiny, __builtin_fminf(__builtin_fminf(c1, q2), q3));
+// One pair's verdict from its four determinants, for a triangle whose valid hits
+// have det > 0 (POS) or det < 0 (!POS).  POS: the smallest of Nb, Ng,
+// det (1 + 1e-5) - (Nb + Ng) and det bound (1 + 1e-5) - Nt; if it is below
+// -band, one of beta >= 0, gamma >= 0, beta <= 1 - gamma, t <= bound certainly
+// fails for the correctly rounded quotients (or det has the sign that makes t
+// negative).  !POS mirrors it: the largest of the four, above +band.  NaNs drop
+// out of v_min3 / v_max3; a pair whose determinants are not finite can never be
+// accepted (t is NaN, 0 or infinite), so any verdict is safe for it.
+template <bool POS>
+__device__ __forceinline__ float tri_verdict(float det, float nb, float ng, float nt, float bound_up, float rel_up) {
+    const float q2 = __builtin_fmaf(det, rel_up, -(nb + ng));
+    const float q3 = __builtin_fmaf(bound_up, det, -nt);
+    if (POS) return __builtin_fminf(__builtin_fminf(__builtin_fminf(nb, ng), q2), q3);
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nb, ng), q2), q3);
 }
 
 }  // namespace
@@ -588,7 +590,11 @@ __global__ void prep_full_records(const RenderParams p, float4* __restrict__ rec
         const float nt = det3(s1, s2, sol);
         rec[(size_t)k * 3 + 0] = make_float4(s1.x, s1.y, s1.z, s2.x);
         rec[(size_t)k * 3 + 1] = make_float4(s2.y, s2.z, sol.x, sol.y);
-        rec[(size_t)k * 3 + 2] = make_float4(sol.z, nt, 0.0f, 0.0f);
+        // |det| <= 6 max|s1| max|s2| max|d| for every pixel; 2^-100 of that is the zero band
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(s1.x), __builtin_fabsf(s1.y)), __builtin_fabsf(s1.z));
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(s2.x), __builtin_fabsf(s2.y)), __builtin_fabsf(s2.z));
+        const float band = 6.1f * m1 * m2 * p.ray_absmax * 0x1p-100f;
+        rec[(size_t)k * 3 + 2] = make_float4(sol.z, nt, band == band ? band : __builtin_inff(), 0.0f);
     } else {
         const M3 m = minors(s2, mk3(-p.w[0], -p.w[1], -p.w[2]));
         rec[(size_t)k * 3 + 0] = make_float4(s1.x, s1.y, s1.z, s2.x);
@@ -641,9 +647,7 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
     }
 
     shared_part = mk3(in_vgpr(shared_part.x), in_vgpr(shared_part.y), in_vgpr(shared_part.z));
-    CandConst kc;
-    kc.one = in_vgpr(1.0f); kc.rel_up = in_vgpr(1.00001f); kc.tiny = in_vgpr(0x1p-100f);
-    kc.absmask = __float_as_uint(in_vgpr(__uint_as_float(0x7fffffffu)));
+    const float rel_up = in_vgpr(1.00001f);
 
     // ---- spheres: object ids 0 .. n_sph-1 ----
     for (uint32_t base = 0; base < p.n_sph; base += kChunkFloat4) {
@@ -699,32 +703,71 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
             const F3 s1 = mk3(q0.x, q0.y, q0.z);
             const F3 s2 = mk3(q0.w, q1.x, q1.y);
             const F3 third = mk3(q1.z, q1.w, q2.x);     // a - eye (pinhole) or a (orthographic)
-            float acc = -1.0f;
+            // The sign of det at a valid hit, the same for the whole wave: +1, -1, or 0 when
+            // no pixel can be accepted (Nt or det is zero or NaN: t is 0, NaN or infinite).
+            bool cand;
             if (PROJ == MRT_PROJ_PERSP) {
-                const float nt = q2.y;
+                const float nt = q2.y, band = q2.z;
+                const float nt_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(nt)));
+                if (nt_u > 0.0f) {
+                    float acc = -__builtin_inff();
 #pragma unroll
-                for (int s = 0; s < kFullSlots; ++s) {
-                    const M3 m = minors(s2, ray[s]);
-                    const float det = expand(s1, m);
-                    const float nb = expand(third, m);
-                    const float ng = expand(s1, minors(third, ray[s]));
-                    acc = __builtin_fmaxf(acc, tri_candidate(det, nb, ng, nt, bound_up[s], kc));
+                    for (int s = 0; s < kFullSlots; ++s) {
+                        const M3 m = minors(s2, ray[s]);
+                        const float det = expand(s1, m);
+                        const float nb = expand(third, m);
+                        const float ng = expand(s1, minors(third, ray[s]));
+                        acc = __builtin_fmaxf(acc, tri_verdict<true>(det, nb, ng, nt, bound_up[s], rel_up));
+                    }
+                    cand = acc >= -band;
+                } else if (nt_u < 0.0f) {
+                    float acc = __builtin_inff();
+#pragma unroll
+                    for (int s = 0; s < kFullSlots; ++s) {
+                        const M3 m = minors(s2, ray[s]);
+                        const float det = expand(s1, m);
+                        const float nb = expand(third, m);
+                        const float ng = expand(s1, minors(third, ray[s]));
+                        acc = __builtin_fminf(acc, tri_verdict<false>(det, nb, ng, nt, bound_up[s], rel_up));
+                    }
+                    cand = acc <= band;
+                } else {
+                    continue;
                 }
             } else {
                 M3 m;
                 m.m0 = q2.y; m.m1 = q2.z; m.m2 = q2.w;
                 const float det = expand(s1, m);
+                const float det_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(det)));
+                const float band = __builtin_fabsf(det) * 0x1p-100f;
+                if (det_u > 0.0f) {
+                    float acc = -__builtin_inff();
 #pragma unroll
-                for (int s = 0; s < kFullSlots; ++s) {
-                    const F3 sol = sub3(third, ray[s]);
-                    const float nb = expand(sol, m);
-                    const float ng = expand(s1, minors(sol, shared_part));
-                    const float nt = expand(s1, minors(s2, sol));
-                    acc = __builtin_fmaxf(acc, tri_candidate(det, nb, ng, nt, bound_up[s], kc));
+                    for (int s = 0; s < kFullSlots; ++s) {
+                        const F3 sol = sub3(third, ray[s]);
+                        const float nb = expand(sol, m);
+                        const float ng = expand(s1, minors(sol, shared_part));
+                        const float nt = expand(s1, minors(s2, sol));
+                        acc = __builtin_fmaxf(acc, tri_verdict<true>(det, nb, ng, nt, bound_up[s], rel_up));
+                    }
+                    cand = acc >= -band;
+                } else if (det_u < 0.0f) {
+                    float acc = __builtin_inff();
+#pragma unroll
+                    for (int s = 0; s < kFullSlots; ++s) {
+                        const F3 sol = sub3(third, ray[s]);
+                        const float nb = expand(sol, m);
+                        const float ng = expand(s1, minors(sol, shared_part));
+                        const float nt = expand(s1, minors(s2, sol));
+                        acc = __builtin_fminf(acc, tri_verdict<false>(det, nb, ng, nt, bound_up[s], rel_up));
+                    }
+                    cand = acc <= band;
+                } else {
+                    continue;
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(acc >= 0.0f) == 0) continue;
-            if (acc >= 0.0f) {
+            if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+            if (cand) {
                 const uint32_t ti = base + g;
                 const float4 va = p.tri_exact[(size_t)ti * 3 + 0];
                 const float4 vb = p.tri_exact[(size_t)ti * 3 + 1];

@@ -47,6 +47,7 @@ struct RenderParams {
     float left, right, top, bottom;
     float xres_f, yres_f;
     float focal;
+    float ray_absmax;               // upper bound of |component| of any primary-ray direction
     float ka, kd, ks;
     float amb[3];
     float bg[3];
