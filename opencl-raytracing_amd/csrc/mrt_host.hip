@@ -146,6 +146,15 @@ inline double permabs(D3 a, D3 b, D3 c) {
 
 const float kAlways = 1e30f;
 
+// The relative rounding budget K assumes normal numbers.  A product that lands in the denormal
+// range is off by up to 2^-150 absolutely instead, and the factor it is multiplied by next
+// scales that; 64 such errors times the largest factor in play is far more than a determinant
+// of these four vectors can collect.
+inline double tiny_abs(D3 a, D3 b, D3 c, D3 d) {
+    auto m = [](D3 v) { return std::fmax(std::fabs(v.x), std::fmax(std::fabs(v.y), std::fabs(v.z))); };
+    return 64.0 * 0x1p-149 * (1.0 + std::fmax(std::fmax(m(a), m(b)), std::fmax(m(c), m(d))));
+}
+
 // One edge function A*x + B*y + C of a triangle record.
 struct Edge { float A, B, C; };
 
@@ -228,11 +237,14 @@ void build_filter_records(const mrt_scene& s, std::vector<float4>& rec) {
             const double sg = T > 0 ? 1.0 : -1.0;
             const D3 P0 = cross(sol, s2), P1 = cross(s1, sol);
             const D3 P2 = n - P0 - P1;
-            const double dU = K * permabs(absv(sol), absv(s2), vabs);
-            const double dV = K * permabs(absv(s1), absv(sol), vabs);
             const double dD = K * permabs(absv(s1), absv(s2), vabs);
             const double maxD = dot(absv(n), vabs);
-            const double m2 = dU + dV + 2 * dD + K * maxD;
+            // A quotient below half the smallest denormal rounds to -0, which the reference's
+            // "beta < 0" lets through: a numerator within 2^-148 |det| of zero must pass too.
+            const double zero_band = maxD * 0x1p-148 + tiny_abs(s1, s2, sol, vabs);
+            const double dU = K * permabs(absv(sol), absv(s2), vabs) + zero_band;
+            const double dV = K * permabs(absv(s1), absv(sol), vabs) + zero_band;
+            const double m2 = dU + dV + 2 * dD + K * maxD + zero_band;
             const Edge e[3] = {
                 make_edge(sg * dot(P0, Vx), sg * dot(P0, Vy), sg * dot(P0, V0), dU, xres, yres),
                 make_edge(sg * dot(P1, Vx), sg * dot(P1, Vy), sg * dot(P1, V0), dV, xres, yres),
@@ -247,9 +259,11 @@ void build_filter_records(const mrt_scene& s, std::vector<float4>& rec) {
             const D3 solabs = absv(a) + vabs;
             const D3 Q0 = cross(s2, d), Q1 = cross(d, s1);
             const D3 a0 = a - V0;   // sol = a0 - Vx*px - Vy*py
-            const double dU = K * permabs(solabs, absv(s2), absv(d));
-            const double dV = K * permabs(absv(s1), solabs, absv(d));
-            const double m2 = dU + dV + 2 * dD + K * std::fabs(Det);
+            // as above: quotients that round to -0, products in the denormal range
+            const double zero_band = std::fabs(Det) * 0x1p-148 + tiny_abs(s1, s2, solabs, absv(d));
+            const double dU = K * permabs(solabs, absv(s2), absv(d)) + zero_band;
+            const double dV = K * permabs(absv(s1), solabs, absv(d)) + zero_band;
+            const double m2 = dU + dV + 2 * dD + K * std::fabs(Det) + zero_band;
             const double u0 = dot(a0, Q0), ux = -dot(Vx, Q0), uy = -dot(Vy, Q0);
             const double v0 = dot(a0, Q1), vx = -dot(Vx, Q1), vy = -dot(Vy, Q1);
             const Edge e[3] = {
@@ -315,6 +329,9 @@ void build_sphere_records(const mrt_scene& s, std::vector<float4>& rec) {
                     lo_v = f * (Y * Z - sy) / den; hi_v = f * (Y * Z + sy) / den;
                     const double dist = std::sqrt(dot(oc, oc));
                     const double dmax2 = f * f + mux * mux + muy * muy;
+                    // b*b and a*c (kernel.cl:250-254) must stay clear of the denormal range, where the
+                    // relative error model of the margin does not hold
+                    if (f * f * r * r < 1e-30) ok = false;
                     // error of b*b - a*c over its gradient at the outline, in pixels
                     margin = 1.0 + K * dist * dmax2 / (r * std::fmin(ux1, uy1) * f);
                 }
@@ -324,6 +341,7 @@ void build_sphere_records(const mrt_scene& s, std::vector<float4>& rec) {
                 lo_v = V - r * 1.001; hi_v = V + r * 1.001;
                 const double reach = std::sqrt(dot(c, c)) + mux + muy + r;
                 margin = 1.0 + K * reach * reach / (r * std::fmin(ux1, uy1));
+                if (r * r < 1e-30) ok = false;      // as for the pinhole camera
             }
             if (ok && std::isfinite(margin) && margin < 1e6) {
                 const double px0 = (lo_u - ux0) / ux1, px1 = (hi_u - ux0) / ux1;

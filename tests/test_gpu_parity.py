@@ -268,6 +268,31 @@ def test_far_from_origin_cancellation(gpu_ctx, mrt, oracle, offset):
         assert np.array_equal(r["rgba"], o["rgba"])
 
 
+def test_negative_zero_barycentric_is_a_hit(mrt, oracle):
+    """beta = Nb/det rounds to -0 when Nb is a negative denormal and det is huge; the reference
+    tests `beta < 0`, which -0 passes, so those pixels hit although they lie (by 1e-43) outside the
+    triangle.  Every kernel must reproduce it: none of the rejection tests may drop a pair on
+    the sign of a numerator alone.  With a viewport 2^130 times larger the same pixels miss."""
+    flag_sets = (0, mrt.FLAG_FULL_TEST, mrt.FLAG_SCREEN_CULL, mrt.FLAG_BLOCK_REJECT, mrt.FLAG_NO_CIRCLE,
+                 mrt.FLAG_NO_PREFILTER)
+    tri = np.array([[0, -0.3, -1, -1e30, -0.3, -1, 0, 0.7, -1]], dtype=np.float64).T
+    for e, expect_all in ((2.0 ** -140, True), (2.0 ** -10, False)):
+        sc = mrt.Scene(eye=[0, 0, 0], u=[1, 0, 0], v=[0, 1, 0], w=[0, 0, 1], xres=4, yres=2, left=-e, right=e,
+                       top=e, bottom=-e, projection=mrt.PROJ_ORTHO, focal=1.0, shader=mrt.SHADER_FLAT,
+                       background=(0, 0, 0), tri=tri, tri_mat=[0], mat=[[1.0], [0.5], [0.25], [4.0]])
+        o = oracle.render(sc)
+        assert bool((o["ids"] == 0).all()) == expect_all
+        assert (o["ids"][:, 0] == 0).all()              # the first column is inside either way
+        for flags in flag_sets:
+            ctx = mrt.Context(device=0, flags=flags)
+            try:
+                r = gpu_render(ctx, sc)
+            finally:
+                ctx.close()
+            assert_same_hits(r, o)
+            assert np.array_equal(r["rgba"], o["rgba"])
+
+
 def test_camera_inside_and_behind_geometry(gpu_ctx, mrt, oracle):
     """Primitives that straddle or lie behind the eye plane, a sphere containing the eye, huge and
     tiny primitives: the prefilter must stay a superset wherever its projection is unbounded."""

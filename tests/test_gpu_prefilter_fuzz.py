@@ -26,7 +26,8 @@ def _scene(mrt, rng, kind, proj):
     if kind == "grazing_hires":     # FP32 noise of the exact test, in pixels, grows with resolution
         xres, yres = int(rng.integers(3000, 8000)), int(rng.integers(24, 48))
     u, v, w = _basis(rng)
-    scale = {"far": 1.0e4, "tiny": 1.0e-3}.get(kind, 1.0) * rng.uniform(0.5, 2.0)
+    scale = {"far": 1.0e4, "tiny": 1.0e-3, "micro": 1.0e-11, "denormal": 1.5e-13,
+             "giant": 1.0e11}.get(kind, 1.0) * rng.uniform(0.5, 2.0)
     eye = rng.uniform(-3, 3, 3) * scale + (rng.uniform(-1, 1, 3) * 3.0e4 if kind == "far" else 0.0)
     focal = rng.uniform(0.3, 3.0)
     depth = rng.uniform(2.0, 8.0) * scale
@@ -64,7 +65,7 @@ def _scene(mrt, rng, kind, proj):
         a = eye + rng.normal(size=(n, 3)) * depth
         b = eye + rng.normal(size=(n, 3)) * depth
         c = eye + rng.normal(size=(n, 3)) * depth
-    else:                           # generic / far / tiny
+    else:                           # generic / far / tiny / micro / denormal / giant
         a = base
         b = a + rng.normal(size=(n, 3)) * depth * 0.15
         c = a + rng.normal(size=(n, 3)) * depth * 0.15
@@ -85,7 +86,7 @@ def _scene(mrt, rng, kind, proj):
 
 
 @pytest.mark.parametrize("kind", ["generic", "needle", "edge_on", "subpixel", "huge", "behind", "far", "tiny",
-                                  "grazing_hires"])
+                                  "grazing_hires", "micro", "denormal", "giant"])
 def test_prefilters_never_drop_an_exact_hit(mrt, kind):
     fast = mrt.Context(device=0)
     blk = mrt.Context(device=0, flags=mrt.FLAG_BLOCK_REJECT)
