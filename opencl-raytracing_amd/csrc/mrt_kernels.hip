@@ -663,16 +663,19 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
         for (uint32_t g = 0; g < count; ++g) {
             const float4 sp = s_rec[g];
             const F3 center = mk3(sp.x, sp.y, sp.z);
-            float acc = -1.0f;
+            // circle_intersect gives up only when the discriminant compares below zero
+            // (kernel.cl:256); a NaN discriminant (NaN radius or centre) goes on, so the test
+            // is "not less than" and not a maximum, which would lose the NaN.
+            bool cand = false;
 #pragma unroll
             for (int s = 0; s < kFullSlots; ++s) {
                 const F3 o = (PROJ == MRT_PROJ_PERSP) ? shared_part : ray[s];
                 const F3 d = (PROJ == MRT_PROJ_PERSP) ? ray[s] : shared_part;
                 float a, b;
-                acc = __builtin_fmaxf(acc, sphere_disc(center, sp.w, o, d, a, b));   // < 0: miss, kernel.cl:256
+                cand |= !(sphere_disc(center, sp.w, o, d, a, b) < 0.0f);
             }
-            if (__builtin_amdgcn_ballot_w64(acc >= 0.0f) == 0) continue;
-            if (acc >= 0.0f) {
+            if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+            if (cand) {
 #pragma unroll
                 for (int s = 0; s < kFullSlots; ++s) {
                     const F3 o = (PROJ == MRT_PROJ_PERSP) ? shared_part : ray[s];

@@ -293,6 +293,42 @@ def test_negative_zero_barycentric_is_a_hit(mrt, oracle):
             assert np.array_equal(r["rgba"], o["rgba"])
 
 
+def test_non_finite_and_odd_inputs(mrt, oracle):
+    """The C ABI takes any floats.  NaN and infinite coordinates, a NaN radius, a negative radius
+    (same sphere, normals pointing inwards: kernel.cl:282-300 divides by the radius), a zero radius
+    and triangles at 1e19 (products overflow to infinity) must come out as the oracle has them,
+    from every kernel."""
+    nan, inf = float("nan"), float("inf")
+    tri = np.array([[0, 0, -3, 1, 0, -3, 0, 1, -3],            # ordinary
+                    [nan, 0, -2, 1, 0, -2, 0, 1, -2],          # NaN vertex
+                    [-1, -1, -2.5, inf, 0, -2.5, 0, 1, -2.5],  # infinite vertex
+                    [-1e19, -1e19, -4, 1e19, -1e19, -4, 0, 1e19, -4],   # overflowing products
+                    [-0.5, -0.5, -1.5, 0.5, -0.5, -1.5, 0, 0.5, -1.5]], dtype=np.float64).T
+    sph = np.array([[-0.8, 0.5, -2, -0.4],      # negative radius
+                    [0.8, 0.5, -2, nan],
+                    [nan, 0, -2, 0.3],
+                    [0.8, -0.5, -2, 0.0],
+                    [0.5, 0.6, -2.2, 0.3]], dtype=np.float64).T
+    flag_sets = (0, mrt.FLAG_FULL_TEST, mrt.FLAG_SCREEN_CULL, mrt.FLAG_BLOCK_REJECT, mrt.FLAG_NO_PREFILTER)
+    for proj in (mrt.PROJ_PERSP, mrt.PROJ_ORTHO):
+        sc = mrt.Scene(eye=[0, 0, 0], u=[1, 0, 0], v=[0, 1, 0], w=[0, 0, 1], xres=96, yres=64, left=-1.2,
+                       right=1.2, top=0.8, bottom=-0.8, projection=proj, focal=1.0, shader=mrt.SHADER_PHONG,
+                       ka=0.2, kd=0.6, ks=0.3, ambient=(1, 1, 1), background=(0.1, 0.2, 0.3), sph=sph,
+                       sph_mat=[0, 1, 0, 1, 1], tri=tri, tri_mat=[0, 1, 0, 1, 0],
+                       mat=[[1.0, 0.2], [0.5, 0.9], [0.25, 0.4], [4.0, 16.0]],
+                       light=[[2.0], [3.0], [1.0], [1.0], [1.0], [1.0]])
+        o = oracle.render(sc)
+        assert len(np.unique(o["ids"])) >= 3          # the NaN-radius sphere "hits" at t = -b/a wherever that is > 0
+        for flags in flag_sets:
+            ctx = mrt.Context(device=0, flags=flags)
+            try:
+                r = gpu_render(ctx, sc)
+            finally:
+                ctx.close()
+            assert_same_hits(r, o)
+            check(r["rgba"], o["rgba"], o["ids"])
+
+
 def test_camera_inside_and_behind_geometry(gpu_ctx, mrt, oracle):
     """Primitives that straddle or lie behind the eye plane, a sphere containing the eye, huge and
     tiny primitives: the prefilter must stay a superset wherever its projection is unbounded."""
