@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""mrraytracer across the GPUs of one node: one process per GPU, interleaved row bands, the
+scene replicated, bands gathered to rank 0 with RCCL, rank 0 writes the PNG.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        opencl-raytracing_amd/host/mrraytracer_dist.py <scene.json> <out.png>
+
+Same scene files, same pixels and the same kind of PNG (8-bit RGB) as the single-GPU
+`mrraytracer` binary (mrraytracer.cpp:23-146 in the reference is the contract both follow);
+rank 0 prints the "raytracing...done" / "writing <file>...done" lines.  Everything that
+computes is in libmrt_hip.so: this script only parses arguments, owns the process group and
+moves buffers.
+
+MRT_DIST_REHEARSAL=1 puts every rank on GPU 0 and gathers over gloo through host memory, to
+exercise the code on a one-GPU machine.  MRT_FLAGS=<integer> as for the binary.
+"""
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+
+BAND_ROWS = 64
+
+
+def main(argv):
+    if len(argv) != 3:
+        print("usage: mrraytracer_dist.py <INPUT-RAYSON-PATH> <OUTPUT-PNG-PATH>   (under torch.distributed.run)",
+              file=sys.stderr)
+        return 255
+    scene_path, png_path = argv[1], argv[2]
+    import torch
+    import torch.distributed as dist
+    import mrt_pkg
+    mrt = mrt_pkg.load()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = os.environ.get("MRT_DIST_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    status = 0
+    try:
+        try:
+            scene = mrt.LoadedScene(path=scene_path)          # every rank parses the file itself
+        except mrt.MrtError as e:
+            if rank == 0:
+                print(f'error loading scene "{scene_path}": {e.message}', file=sys.stderr)
+            return 1
+        st = scene.struct
+        if rank == 0:
+            print("raytracing...", end="", flush=True)
+        ctx = mrt.Context(device=dev_index, flags=int(os.environ.get("MRT_FLAGS", "0"), 0))
+        try:
+            ctx.set_scene(scene)
+            rows = [mrt.band_rows(st.yres, BAND_ROWS, r, world) for r in range(world)]
+            stride = max(max(rows) * st.xres * 4, 4)
+            local = torch.empty(stride, dtype=torch.uint8, device=dev)
+            ctx.render_bands_device(BAND_ROWS, rank, world, local.data_ptr(), local.numel(),
+                                    stream=torch.cuda.current_stream(dev).cuda_stream)
+            if world == 1:
+                gathered = local.cpu().numpy().reshape(1, stride)
+            elif rehearsal:
+                parts = [torch.empty(stride, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+                dist.gather(local.cpu(), parts, dst=0)
+                gathered = torch.stack(parts).numpy() if rank == 0 else None
+            else:
+                parts = [torch.empty(stride, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+                dist.gather(local, parts, dst=0)              # RCCL over xGMI
+                gathered = torch.stack(parts).cpu().numpy() if rank == 0 else None
+        finally:
+            ctx.close()
+        if rank == 0:
+            print("done", flush=True)
+            image = mrt.bands_to_image(gathered, stride, st.xres, st.yres, BAND_ROWS, world)
+            print(f"writing {png_path}...", end="", flush=True)
+            mrt.write_png_rgb(png_path, image)
+            print("done\n", flush=True)
+    except mrt.MrtError as e:
+        print(f"\nerror: render failed: {e.message}", file=sys.stderr)
+        status = 1
+    finally:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    return status
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

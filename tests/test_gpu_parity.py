@@ -539,3 +539,33 @@ def test_cli_end_to_end(tmp_path):
             rgb = np.asarray(im)
         rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=-1)
         check(rgba, g["rgba"], g["ids"])
+
+
+def test_dist_cli_two_ranks_on_one_gpu(tmp_path):
+    """mrraytracer_dist.py (one process per GPU, bands gathered to rank 0) with two ranks that
+    share GPU 0 and gather over gloo: same stdout contract and the same pixels as the binary."""
+    import os
+    import sys
+    from PIL import Image
+    script = ROOT / "opencl-raytracing_amd" / "host" / "mrraytracer_dist.py"
+    name = "teatime"
+    out = tmp_path / "dist.png"
+    env = dict(os.environ, MRT_DIST_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script),
+                        str(SCENES / f"{name}.json"), str(out)], capture_output=True, text=True, env=env,
+                       timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"raytracing...done\nwriting {out}...done\n\n" in r.stdout
+    g = np.load(GOLDEN / f"{name}.npz")
+    with Image.open(out) as im:
+        assert im.mode == "RGB"
+        rgb = np.asarray(im)
+    rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=-1)
+    check(rgba, g["rgba"], g["ids"])
+    # a scene file that does not load: every rank exits 1, rank 0 reports it
+    bad = tmp_path / "bad.json"
+    bad.write_text("[1, 2]")
+    r = subprocess.run([sys.executable, str(script), str(bad), str(out)], capture_output=True, text=True, env=env,
+                       timeout=120)
+    assert r.returncode == 1 and "rayson must be comprised of one JSON object" in r.stderr
