@@ -116,6 +116,50 @@ __device__ __forceinline__ void exact_pass(const RenderParams& p, uint32_t mask,
     }
 }
 
+// As exact_pass, for a kernel that keeps the closest hit of its 16 pixels in registers and the
+// uv components of its four columns and four rows too: nothing in the loop touches memory.
+// Slot s = 4*row + column is visited when some lane of the wave has its bit set.
+template <int PROJ, bool TRI>
+__device__ __forceinline__ void exact_slots(const RenderParams& p, uint32_t mask, uint32_t prim,
+                                            const float (&ux)[kLanePx], const float (&uy)[kLanePx],
+                                            float (&best_t)[kLanePx * kLanePx], int32_t (&best_id)[kLanePx * kLanePx],
+                                            unsigned long long& n_exact) {
+    const float t_lower = 0.0f;   // scene::intersect, gfxraytrace.hpp:812
+    F3 A, B, C;
+    float radius = 0.0f;
+    if (TRI) {
+        const float4 va = p.tri_exact[(size_t)prim * 3 + 0];
+        const float4 vb = p.tri_exact[(size_t)prim * 3 + 1];
+        const float4 vc = p.tri_exact[(size_t)prim * 3 + 2];
+        A = mk3(va.x, va.y, va.z); B = mk3(vb.x, vb.y, vb.z); C = mk3(vc.x, vc.y, vc.z);
+    } else {
+        const float4 sp = p.sph[prim];
+        A = mk3(sp.x, sp.y, sp.z); B = A; C = A;
+        radius = sp.w;
+    }
+    const int32_t obj_id = (int32_t)(TRI ? p.n_sph + prim : prim);   // spheres first, gfxraytrace.hpp:701-714
+#pragma unroll
+    for (int s = 0; s < kLanePx * kLanePx; ++s) {
+        const bool mine = (mask >> s) & 1u;
+        if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
+        if (mine) {
+            F3 o, d;
+            pixel_ray<PROJ>(p, ux[s & 3], uy[s >> 2], o, d);
+            float t;
+            bool hit, two;
+            // tri_intersect / circle_intersect against the current bound (kernel.cl:324,341),
+            // then the loop's strict acceptance (:326,:344).
+            if (TRI) hit = tri_exact(A, B, C, o, d, best_t[s], t_lower, t);
+            else hit = sphere_exact(A, radius, o, d, best_t[s], t_lower, t, two);
+            if (hit && t > t_lower && t < best_t[s]) {
+                best_t[s] = t;
+                best_id[s] = obj_id;
+            }
+            ++n_exact;
+        }
+    }
+}
+
 }  // namespace
 
 template <int PROJ, bool BLOCK_REJECT>
@@ -394,11 +438,20 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
     const float yf0 = tyf + (float)((lane >> 3) * kLanePx);
     const float tile_span = (float)(kWaveTile - 1);
 
+    // Closest hit so far (t = FLT_MAX, gfxraytrace.hpp:813) and the uv components of this lane's
+    // columns and rows (gfxraytrace.hpp:850-852: the pixel grid is (x + 1, y + 1)) stay in registers.
+    float best_t[kLanePx * kLanePx], ux[kLanePx], uy[kLanePx];
+    int32_t best_id[kLanePx * kLanePx];
+    {
+        const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
 #pragma unroll
-    for (int j = 0; j < kLanePx; ++j) {
-        const size_t off = (size_t)(lr0 + j) * pitch + x0;
-        *reinterpret_cast<float4*>(t_out + off) = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX);
-        *reinterpret_cast<int4*>(id_out + off) = make_int4(-1, -1, -1, -1);
+        for (int k = 0; k < kLanePx; ++k) {
+            const uint32_t lr = lr0 + k;
+            ux[k] = uv_component(p.left, p.right, (float)(x0 + k) + 1.0f, p.xres_f);
+            uy[k] = uv_component(p.bottom, p.top, (float)image_row(p, lr < last_row ? lr : last_row) + 1.0f, p.yres_f);
+        }
+#pragma unroll
+        for (int s = 0; s < kLanePx * kLanePx; ++s) { best_t[s] = FLT_MAX; best_id[s] = -1; }
     }
     unsigned long long n_exact = 0;
 
@@ -427,7 +480,7 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
                 }
                 dup += f.x;
             }
-            exact_pass<PROJ, false>(p, mask, si, x0, lr0, t_out, id_out, pitch, n_exact);
+            exact_slots<PROJ, false>(p, mask, si, ux, uy, best_t, best_id, n_exact);
         }
     }
 
@@ -484,20 +537,23 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
                     v0 += a0; v1 += a1; v2 += a2;
                 }
             }
-            exact_pass<PROJ, true>(p, mask, ti, x0, lr0, t_out, id_out, pitch, n_exact);
+            if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
+            exact_slots<PROJ, true>(p, mask, ti, ux, uy, best_t, best_id, n_exact);
         }
     }
 
 #pragma unroll
     for (int j = 0; j < kLanePx; ++j) {
         const size_t off = (size_t)(lr0 + j) * pitch + x0;
-        float4 tv = *reinterpret_cast<const float4*>(t_out + off);
-        const int4 iv = *reinterpret_cast<const int4*>(id_out + off);
-        tv.x = iv.x < 0 ? -1.0f : tv.x;
-        tv.y = iv.y < 0 ? -1.0f : tv.y;
-        tv.z = iv.z < 0 ? -1.0f : tv.z;
-        tv.w = iv.w < 0 ? -1.0f : tv.w;
+        int4 iv;
+        float4 tv;
+        iv.x = best_id[j * 4 + 0]; iv.y = best_id[j * 4 + 1]; iv.z = best_id[j * 4 + 2]; iv.w = best_id[j * 4 + 3];
+        tv.x = iv.x < 0 ? -1.0f : best_t[j * 4 + 0];          // intersect.t_ of a miss, kernel.cl:363
+        tv.y = iv.y < 0 ? -1.0f : best_t[j * 4 + 1];
+        tv.z = iv.z < 0 ? -1.0f : best_t[j * 4 + 2];
+        tv.w = iv.w < 0 ? -1.0f : best_t[j * 4 + 3];
         *reinterpret_cast<float4*>(t_out + off) = tv;
+        *reinterpret_cast<int4*>(id_out + off) = iv;
     }
     if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time of one scene under a list of mrt_config flag sets (GPU box only).
 
-usage: time_flags.py [teatime|soup] XRES YRES FLAGS [FLAGS ...]     (FLAGS are integers)
+usage: time_flags.py [teatime|soup|<scene.json>] XRES YRES FLAGS [FLAGS ...]     (FLAGS are integers)
 """
 import sys
 from pathlib import Path
@@ -15,8 +15,11 @@ import mkscene  # noqa: E402
 
 mrt = mrt_pkg.load()
 kind, xres, yres = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-text = mkscene.teatime(xres, yres) if kind == "teatime" else mkscene.soup(xres, yres)
-scene = mrt.LoadedScene(text=text).copy()
+if kind.endswith(".json"):          # any scene file, at the requested resolution
+    scene = mrt.LoadedScene(path=kind).copy().with_resolution(xres, yres)
+else:
+    text = mkscene.teatime(xres, yres) if kind == "teatime" else mkscene.soup(xres, yres)
+    scene = mrt.LoadedScene(text=text).copy()
 out = torch.empty(xres * yres, dtype=torch.int32, device="cuda:0")
 for flags in (int(a, 0) for a in sys.argv[4:]):
     ctx = mrt.Context(device=0, flags=flags)
