@@ -62,6 +62,63 @@ __device__ __forceinline__ void stage_chunk(float4* dst, const float4* __restric
         dst[tid + k * kBlockThreads] = src[tid + k * kBlockThreads];
 }
 
+// The colour of pixel (x, y) given its closest hit (t, object id; id < 0: no hit): rebuilds
+// the hit record tri_intersect / circle_intersect would have returned, shades it (flat_shader /
+// phong_shader, kernel.cl:381-445) and converts to bytes (gfximage.hpp:46-51).  RGBA8, A = 255.
+template <int PROJ>
+__device__ __forceinline__ uint32_t shade_pixel(const RenderParams& p, uint32_t x, uint32_t y, float t, int32_t id) {
+    float r, g, b;
+    if (id < 0) {
+        // kernel.cl:384-389 / :441-444.
+        r = p.bg[0]; g = p.bg[1]; b = p.bg[2];
+    } else {
+        const F3 eye = mk3(p.eye[0], p.eye[1], p.eye[2]);
+        const float ux = uv_component(p.left, p.right, (float)x + 1.0f, p.xres_f);
+        const float uy = uv_component(p.bottom, p.top, (float)y + 1.0f, p.yres_f);
+        F3 o, d;
+        pixel_ray<PROJ>(p, ux, uy, o, d);
+        // kernel.cl:224 / :270 / :289: location = origin + direction * t.
+        const F3 loc = add3(o, scale3(d, t));
+        F3 n;
+        uint32_t mat;
+        if ((uint32_t)id < p.n_sph) {
+            const float4 sp = p.sph[id];
+            const F3 center = mk3(sp.x, sp.y, sp.z);
+            float a, bq;
+            const float disc = sphere_disc(center, sp.w, o, d, a, bq);
+            // kernel.cl:271 (two roots) vs :290 (tangent).
+            if (disc > 0) n = normalize3(div3(sub3(loc, center), sp.w));
+            else n = normalize3(sub3(loc, center));
+            mat = p.sph_mat[id];
+        } else {
+            const uint32_t ti = (uint32_t)id - p.n_sph;
+            const float4 va = p.tri_exact[(size_t)ti * 3 + 0];
+            const float4 vb = p.tri_exact[(size_t)ti * 3 + 1];
+            const float4 vc = p.tri_exact[(size_t)ti * 3 + 2];
+            const F3 A = mk3(va.x, va.y, va.z);
+            // kernel.cl:225-227.
+            n = normalize3(cross3(sub3(A, mk3(vb.x, vb.y, vb.z)), sub3(A, mk3(vc.x, vc.y, vc.z))));
+            mat = __float_as_uint(va.w);
+        }
+        const float4 m = p.mats[mat];
+        const F3 color = mk3(m.x, m.y, m.z);
+        if (p.shader == MRT_SHADER_FLAT) {
+            r = color.x; g = color.y; b = color.z;           // kernel.cl:392-394
+        } else {
+            r = p.ka * p.amb[0];                             // kernel.cl:404-406
+            g = p.ka * p.amb[1];
+            b = p.ka * p.amb[2];
+            for (uint32_t l = 0; l < p.n_lights; ++l) {
+                const float4 lp = p.lights[2 * l], lc = p.lights[2 * l + 1];
+                phong_light(loc, n, color, m.w, eye, mk3(lp.x, lp.y, lp.z), mk3(lc.x, lc.y, lc.z),
+                            p.kd, p.ks, r, g, b);
+            }
+            r = clamp01(r); g = clamp01(g); b = clamp01(b);
+        }
+    }
+    return (to_byte(r) & 0xFFu) | ((to_byte(g) & 0xFFu) << 8) | ((to_byte(b) & 0xFFu) << 16) | 0xFF000000u;
+}
+
 // Exact test of one primitive against the pixels of this lane's 4x4 block
 // whose bit is set in mask (bit r = row r/4, column r%4).  The closest hit so
 // far lives in the (t, id) planes in global memory -- each pixel belongs to
@@ -400,6 +457,26 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
             tv.z = iv.z < 0 ? -1.0f : tv.z;
             tv.w = iv.w < 0 ? -1.0f : tv.w;
             *reinterpret_cast<float4*>(t_out + off) = tv;
+            // Shade this row segment here rather than in a second launch: four pixels, one
+            // aligned 16-byte RGBA8 store per lane, 128 contiguous bytes per lane row of the wave.
+            const uint32_t lr = lr0 + j;
+            if (p.fuse_shade && lr < p.local_rows && x0 < p.xres) {
+                const uint32_t y = image_row(p, lr);
+                const float tt[4] = {tv.x, tv.y, tv.z, tv.w};
+                const int32_t ii[4] = {iv.x, iv.y, iv.z, iv.w};
+                uint32_t px[4];
+#pragma unroll
+                for (int i = 0; i < kLanePx; ++i)
+                    px[i] = (x0 + i < p.xres) ? shade_pixel<PROJ>(p, x0 + i, y, tt[i], ii[i]) : 0u;
+                uint32_t* dst = p.out + (size_t)lr * p.xres + x0;
+                if (p.fuse_shade == 2) {
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kLanePx; ++i)
+                        if (x0 + i < p.xres) dst[i] = px[i];
+                }
+            }
         }
         if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
     }
@@ -876,67 +953,8 @@ __global__ __launch_bounds__(256) void shade_kernel(const RenderParams p,
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
     const uint32_t lr = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= p.xres || lr >= p.local_rows) return;
-    const uint32_t y = image_row(p, lr);
     const size_t src = (size_t)lr * pitch + x;
-    const int32_t id = id_in[src];
-    const float t = t_in[src];
-
-    float r, g, b;
-    if (id < 0) {
-        // kernel.cl:384-389 / :441-444.
-        r = p.bg[0]; g = p.bg[1]; b = p.bg[2];
-    } else {
-        const F3 eye = mk3(p.eye[0], p.eye[1], p.eye[2]);
-        const F3 cu = mk3(p.u[0], p.u[1], p.u[2]);
-        const F3 cv = mk3(p.v[0], p.v[1], p.v[2]);
-        const F3 cw = mk3(p.w[0], p.w[1], p.w[2]);
-        const float ux = uv_component(p.left, p.right, (float)x + 1.0f, p.xres_f);
-        const float uy = uv_component(p.bottom, p.top, (float)y + 1.0f, p.yres_f);
-        F3 o, d;
-        if (PROJ == MRT_PROJ_PERSP) persp_ray(eye, cu, cv, cw, p.focal, ux, uy, o, d);
-        else ortho_ray(cu, cv, cw, ux, uy, o, d);
-        // kernel.cl:224 / :270 / :289: location = origin + direction * t.
-        const F3 loc = add3(o, scale3(d, t));
-        F3 n;
-        uint32_t mat;
-        if ((uint32_t)id < p.n_sph) {
-            const float4 sp = p.sph[id];
-            const F3 center = mk3(sp.x, sp.y, sp.z);
-            float a, bq;
-            const float disc = sphere_disc(center, sp.w, o, d, a, bq);
-            // kernel.cl:271 (two roots) vs :290 (tangent).
-            if (disc > 0) n = normalize3(div3(sub3(loc, center), sp.w));
-            else n = normalize3(sub3(loc, center));
-            mat = p.sph_mat[id];
-        } else {
-            const uint32_t ti = (uint32_t)id - p.n_sph;
-            const float4 va = p.tri_exact[(size_t)ti * 3 + 0];
-            const float4 vb = p.tri_exact[(size_t)ti * 3 + 1];
-            const float4 vc = p.tri_exact[(size_t)ti * 3 + 2];
-            const F3 A = mk3(va.x, va.y, va.z);
-            // kernel.cl:225-227.
-            n = normalize3(cross3(sub3(A, mk3(vb.x, vb.y, vb.z)), sub3(A, mk3(vc.x, vc.y, vc.z))));
-            mat = __float_as_uint(va.w);
-        }
-        const float4 m = p.mats[mat];
-        const F3 color = mk3(m.x, m.y, m.z);
-        if (p.shader == MRT_SHADER_FLAT) {
-            r = color.x; g = color.y; b = color.z;           // kernel.cl:392-394
-        } else {
-            r = p.ka * p.amb[0];                             // kernel.cl:404-406
-            g = p.ka * p.amb[1];
-            b = p.ka * p.amb[2];
-            for (uint32_t l = 0; l < p.n_lights; ++l) {
-                const float4 lp = p.lights[2 * l], lc = p.lights[2 * l + 1];
-                phong_light(loc, n, color, m.w, eye, mk3(lp.x, lp.y, lp.z), mk3(lc.x, lc.y, lc.z),
-                            p.kd, p.ks, r, g, b);
-            }
-            r = clamp01(r); g = clamp01(g); b = clamp01(b);
-        }
-    }
-    const uint32_t px = (to_byte(r) & 0xFFu) | ((to_byte(g) & 0xFFu) << 8) |
-                        ((to_byte(b) & 0xFFu) << 16) | 0xFF000000u;
-    p.out[(size_t)lr * p.xres + x] = px;
+    p.out[(size_t)lr * p.xres + x] = shade_pixel<PROJ>(p, x, image_row(p, lr), t_in[src], id_in[src]);
 }
 
 template __global__ void trace_kernel<MRT_PROJ_ORTHO, false>(const RenderParams, float*, int32_t*, uint32_t);
