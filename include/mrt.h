@@ -125,8 +125,8 @@ enum {
 typedef struct mrt_stats {
     double upload_ms;       /* scene H2D + per-frame setup (set_scene)          */
     double kernel_ms;       /* device time of both render kernels (HIP events)  */
-    double trace_ms;        /* ... of the closest-hit kernel (the default one also shades) */
-    double shade_ms;        /* ... of the separate shading kernel; 0 when the closest-hit kernel shades */
+    double trace_ms;        /* ... of the closest-hit kernel, which also shades  */
+    double shade_ms;        /* 0: shading is part of the closest-hit kernel      */
     double download_ms;     /* D2H of the pixels (0 for device-resident output) */
     uint64_t rays;          /* primary rays = pixels rendered                   */
     uint64_t prim_tests;    /* rays x (n_spheres + n_tris), brute force         */

@@ -27,8 +27,6 @@ __global__ void full_trace_kernel(const RenderParams p, const float4* full_rec, 
                                   uint32_t pitch);
 template <int PROJ>
 __global__ void prep_full_records(const RenderParams p, float4* rec);
-template <int PROJ>
-__global__ void shade_kernel(const RenderParams p, const float* t_in, const int32_t* id_in, uint32_t pitch);
 }  // namespace mrt
 
 using mrt::RenderParams;
@@ -513,18 +511,14 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
 
     const dim3 tgrid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY);
     const dim3 fgrid(pitch / mrt::kBlockTileX, prow / 32);      // full_trace_kernel: blocks of 64 x 32 pixels
-    const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
     // The block reject needs a lane's four rows to be consecutive image rows.
     const bool block = (ctx->flags & MRT_FLAG_BLOCK_REJECT) && (band_rows % 4 == 0);
     const bool persp = ctx->projection == MRT_PROJ_PERSP;
     const dim3 tb(mrt::kBlockThreads);
-    // trace_kernel shades its own pixels (one launch per frame); the other kernels leave that
-    // to shade_kernel.  16-byte stores need rows and buffer aligned to four pixels.
-    const bool own_shade = !(ctx->flags & MRT_FLAG_FULL_TEST) &&
-                           !((ctx->flags & MRT_FLAG_SCREEN_CULL) && !(ctx->flags & MRT_FLAG_NO_PREFILTER) &&
-                             (band_rows % mrt::kWaveTile == 0));
-    p.fuse_shade = !own_shade ? 0u : ((p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u);
+    // Every closest-hit kernel shades its own pixels in its epilogue (one launch per frame);
+    // 16-byte stores need rows and buffer aligned to four pixels.
+    p.fuse_shade = (p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u;
     // The tile cull needs a wave tile's 32 rows to be consecutive image rows, and it has no
     // exact-only mode of its own.
     const bool cull = (ctx->flags & MRT_FLAG_SCREEN_CULL) && !(ctx->flags & MRT_FLAG_NO_PREFILTER) &&
@@ -549,13 +543,6 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
     HIP_TRY(ctx, hipGetLastError());
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
-    if (!p.fuse_shade) {
-        if (ctx->projection == MRT_PROJ_PERSP)
-            hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_PERSP>, sgrid, dim3(256), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
-        else
-            hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_ORTHO>, sgrid, dim3(256), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
-        HIP_TRY(ctx, hipGetLastError());
-    }
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
     return MRT_OK;
 }

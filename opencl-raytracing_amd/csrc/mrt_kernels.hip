@@ -1,23 +1,30 @@
 // mrt_kernels.hip -- CDNA4 (gfx950) device code of the fused render path.
 //
-// Two launches per frame replace the reference's four stage kernels and the
-// host round trips between them (gfxraytrace.hpp:830-878):
+// One launch per frame replaces the reference's four stage kernels and the
+// host round trips between them (gfxraytrace.hpp:830-878): primary-ray
+// generation + brute-force closest hit over every sphere and triangle (kernels
+// uv / *_viewrays / intersections, kernel.cl:123-379), then, in the same
+// kernel's epilogue, shade_pixel rebuilds the winning hit record, shades it
+// (flat_shader / phong_shader, kernel.cl:381-445), converts to bytes
+// (gfximage.hpp:46-51) and writes coalesced RGBA8.  (t, object id) per pixel
+// are also written to two planes for callers that ask for them.
 //
-//   trace_kernel  primary-ray generation + brute-force closest hit over every
-//                 sphere and triangle (kernels uv / *_viewrays / intersections,
-//                 kernel.cl:123-379).  Writes (t, object id) per pixel.
-//   shade_kernel  rebuilds the winning hit record and shades it (flat_shader /
-//                 phong_shader, kernel.cl:381-445), converts to bytes
-//                 (gfximage.hpp:46-51) and writes coalesced RGBA8.
+// Three kernels implement the closest-hit loop, selected by mrt_config.flags;
+// all give the same winners, t and bytes:
 //
-// trace_kernel is the hot loop: pixels x primitives tests, no acceleration
-// structure.  Per (pixel, triangle) it evaluates three affine edge functions
-// of the pixel coordinate (primary rays of a pinhole or orthographic camera
-// are affine in the pixel, so the numerators of Cramer's rule are too) and
-// rejects the pair when any is below a per-edge error margin.  The few pairs
-// that survive run the reference arithmetic (mrt_device.hpp), in object
-// order, so the accepted hits, their t and the winner are those of the
-// reference loop.  Spheres always run the reference discriminant.
+//   trace_kernel       the default.  Per (pixel, triangle) it tests a bounding
+//                      circle, then three affine edge functions of the pixel
+//                      coordinate (primary rays of a pinhole or orthographic
+//                      camera are affine in the pixel, so the numerators of
+//                      Cramer's rule are too) and rejects the pair when one is
+//                      below a per-edge error margin.  The few pairs that
+//                      survive run the reference arithmetic (mrt_device.hpp),
+//                      in object order, so the accepted hits, their t and the
+//                      winner are those of the reference loop.
+//   full_trace_kernel  MRT_FLAG_FULL_TEST: the reference's determinants for
+//                      every pair, divisions deferred.
+//   cull_trace_kernel  MRT_FLAG_SCREEN_CULL (opt-in): lanes first test 64
+//                      primitives each against the whole wave tile.
 #include "mrt.h"
 #include "mrt_device.hpp"
 #include "mrt_kernels.hpp"
@@ -117,6 +124,27 @@ __device__ __forceinline__ uint32_t shade_pixel(const RenderParams& p, uint32_t 
         }
     }
     return (to_byte(r) & 0xFFu) | ((to_byte(g) & 0xFFu) << 8) | ((to_byte(b) & 0xFFu) << 16) | 0xFF000000u;
+}
+
+// Shades one lane row segment of four pixels starting at (x0, local row lr) and writes it to
+// the RGBA8 output: one aligned 16-byte store when p.fuse_shade == 2, single pixels otherwise.
+template <int PROJ>
+__device__ __forceinline__ void shade_row4(const RenderParams& p, uint32_t x0, uint32_t lr, float4 tv, int4 iv) {
+    if (!(lr < p.local_rows && x0 < p.xres)) return;
+    const uint32_t y = image_row(p, lr);
+    const float tt[4] = {tv.x, tv.y, tv.z, tv.w};
+    const int32_t ii[4] = {iv.x, iv.y, iv.z, iv.w};
+    uint32_t px[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) px[i] = (x0 + i < p.xres) ? shade_pixel<PROJ>(p, x0 + i, y, tt[i], ii[i]) : 0u;
+    uint32_t* dst = p.out + (size_t)lr * p.xres + x0;
+    if (p.fuse_shade == 2) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (x0 + i < p.xres) dst[i] = px[i];
+    }
 }
 
 // Exact test of one primitive against the pixels of this lane's 4x4 block
@@ -459,24 +487,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
             *reinterpret_cast<float4*>(t_out + off) = tv;
             // Shade this row segment here rather than in a second launch: four pixels, one
             // aligned 16-byte RGBA8 store per lane, 128 contiguous bytes per lane row of the wave.
-            const uint32_t lr = lr0 + j;
-            if (p.fuse_shade && lr < p.local_rows && x0 < p.xres) {
-                const uint32_t y = image_row(p, lr);
-                const float tt[4] = {tv.x, tv.y, tv.z, tv.w};
-                const int32_t ii[4] = {iv.x, iv.y, iv.z, iv.w};
-                uint32_t px[4];
-#pragma unroll
-                for (int i = 0; i < kLanePx; ++i)
-                    px[i] = (x0 + i < p.xres) ? shade_pixel<PROJ>(p, x0 + i, y, tt[i], ii[i]) : 0u;
-                uint32_t* dst = p.out + (size_t)lr * p.xres + x0;
-                if (p.fuse_shade == 2) {
-                    *reinterpret_cast<uint4*>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < kLanePx; ++i)
-                        if (x0 + i < p.xres) dst[i] = px[i];
-                }
-            }
+            if (p.fuse_shade) shade_row4<PROJ>(p, x0, lr0 + j, tv, iv);
         }
         if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
     }
@@ -631,6 +642,7 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
         tv.w = iv.w < 0 ? -1.0f : best_t[j * 4 + 3];
         *reinterpret_cast<float4*>(t_out + off) = tv;
         *reinterpret_cast<int4*>(id_out + off) = iv;
+        if (p.fuse_shade) shade_row4<PROJ>(p, x0, lr0 + j, tv, iv);
     }
     if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
 }
@@ -937,24 +949,11 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
             tv.w = iv.w < 0 ? -1.0f : best_t[j * 4 + 3];
             *reinterpret_cast<float4*>(t_out + off) = tv;
             *reinterpret_cast<int4*>(id_out + off) = iv;
+            if (p.fuse_shade) shade_row4<PROJ>(p, x0, lr0 + j, tv, iv);
         }
         if (p.exact_counter != nullptr)
             atomicAdd(p.exact_counter, (unsigned long long)kFullSlots * ((unsigned long long)p.n_sph + p.n_tri));
     }
-}
-
-// One thread per pixel; consecutive lanes take consecutive pixels of a row so
-// each wave writes 256 contiguous bytes of RGBA8.
-template <int PROJ>
-__global__ __launch_bounds__(256) void shade_kernel(const RenderParams p,
-                                                   const float* __restrict__ t_in,
-                                                   const int32_t* __restrict__ id_in,
-                                                   uint32_t pitch) {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t lr = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= p.xres || lr >= p.local_rows) return;
-    const size_t src = (size_t)lr * pitch + x;
-    p.out[(size_t)lr * p.xres + x] = shade_pixel<PROJ>(p, x, image_row(p, lr), t_in[src], id_in[src]);
 }
 
 template __global__ void trace_kernel<MRT_PROJ_ORTHO, false>(const RenderParams, float*, int32_t*, uint32_t);
@@ -967,7 +966,5 @@ template __global__ void prep_full_records<MRT_PROJ_ORTHO>(const RenderParams, f
 template __global__ void prep_full_records<MRT_PROJ_PERSP>(const RenderParams, float4*);
 template __global__ void cull_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void cull_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, float*, int32_t*, uint32_t);
-template __global__ void shade_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float*, const int32_t*, uint32_t);
-template __global__ void shade_kernel<MRT_PROJ_PERSP>(const RenderParams, const float*, const int32_t*, uint32_t);
 
 }  // namespace mrt

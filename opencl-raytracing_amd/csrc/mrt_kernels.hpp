@@ -53,7 +53,7 @@ struct RenderParams {
     float bg[3];
     int32_t shader;
     uint32_t flags;
-    uint32_t fuse_shade;            // trace_kernel shades too: 0 no, 1 scalar stores, 2 aligned 16-byte stores
+    uint32_t fuse_shade;            // RGBA8 stores of the epilogue: 0 none (planes only), 1 single pixels, 2 aligned 16 bytes
     uint32_t xres, yres;            // whole image
     uint32_t band_rows, rank, world;  // interleaved row-band partition
     uint32_t local_rows;            // rows this launch renders (packed)
