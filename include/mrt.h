@@ -126,7 +126,7 @@ typedef struct mrt_stats {
     double upload_ms;       /* scene H2D + per-frame setup (set_scene)          */
     double kernel_ms;       /* device time of both render kernels (HIP events)  */
     double trace_ms;        /* ... of the closest-hit kernel, which also shades  */
-    double shade_ms;        /* 0: shading is part of the closest-hit kernel      */
+    double shade_ms;        /* ... of the separate shading launch (tile cull only), else 0 */
     double download_ms;     /* D2H of the pixels (0 for device-resident output) */
     uint64_t rays;          /* primary rays = pixels rendered                   */
     uint64_t prim_tests;    /* rays x (n_spheres + n_tris), brute force         */

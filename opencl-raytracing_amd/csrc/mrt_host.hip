@@ -27,6 +27,8 @@ __global__ void full_trace_kernel(const RenderParams p, const float4* full_rec, 
                                   uint32_t pitch);
 template <int PROJ>
 __global__ void prep_full_records(const RenderParams p, float4* rec);
+template <int PROJ>
+__global__ void shade_kernel(const RenderParams p, const float* t_in, const int32_t* id_in, uint32_t pitch);
 }  // namespace mrt
 
 using mrt::RenderParams;
@@ -516,13 +518,15 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     const bool block = (ctx->flags & MRT_FLAG_BLOCK_REJECT) && (band_rows % 4 == 0);
     const bool persp = ctx->projection == MRT_PROJ_PERSP;
     const dim3 tb(mrt::kBlockThreads);
-    // Every closest-hit kernel shades its own pixels in its epilogue (one launch per frame);
-    // 16-byte stores need rows and buffer aligned to four pixels.
-    p.fuse_shade = (p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u;
     // The tile cull needs a wave tile's 32 rows to be consecutive image rows, and it has no
     // exact-only mode of its own.
     const bool cull = (ctx->flags & MRT_FLAG_SCREEN_CULL) && !(ctx->flags & MRT_FLAG_NO_PREFILTER) &&
                       (band_rows % mrt::kWaveTile == 0);
+    // trace_kernel and full_trace_kernel shade their own pixels in the epilogue (one launch per
+    // frame); 16-byte stores need rows and buffer aligned to four pixels.  The tile cull runs at
+    // low occupancy and leaves shading to shade_kernel.
+    const bool full = (ctx->flags & MRT_FLAG_FULL_TEST) != 0;
+    p.fuse_shade = (cull && !full) ? 0u : ((p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u);
     if ((ctx->flags & MRT_FLAG_FULL_TEST) && persp)
         hipLaunchKernelGGL((mrt::full_trace_kernel<MRT_PROJ_PERSP>), fgrid, tb, 0, stream, p,
                            (const float4*)ctx->d_full_rec, ctx->d_t, ctx->d_id, pitch);
@@ -543,6 +547,14 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
     HIP_TRY(ctx, hipGetLastError());
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
+    if (!p.fuse_shade) {
+        const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
+        if (persp)
+            hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_PERSP>, sgrid, dim3(256), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+        else
+            hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_ORTHO>, sgrid, dim3(256), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
     return MRT_OK;
 }

@@ -7,7 +7,8 @@
 // kernel's epilogue, shade_pixel rebuilds the winning hit record, shades it
 // (flat_shader / phong_shader, kernel.cl:381-445), converts to bytes
 // (gfximage.hpp:46-51) and writes coalesced RGBA8.  (t, object id) per pixel
-// are also written to two planes for callers that ask for them.
+// are also written to two planes for callers that ask for them and for
+// shade_kernel, the separate shading launch cull_trace_kernel uses.
 //
 // Three kernels implement the closest-hit loop, selected by mrt_config.flags;
 // all give the same winners, t and bytes:
@@ -641,8 +642,7 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
         tv.z = iv.z < 0 ? -1.0f : best_t[j * 4 + 2];
         tv.w = iv.w < 0 ? -1.0f : best_t[j * 4 + 3];
         *reinterpret_cast<float4*>(t_out + off) = tv;
-        *reinterpret_cast<int4*>(id_out + off) = iv;
-        if (p.fuse_shade) shade_row4<PROJ>(p, x0, lr0 + j, tv, iv);
+        *reinterpret_cast<int4*>(id_out + off) = iv;       // shade_kernel takes it from here
     }
     if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
 }
@@ -956,6 +956,21 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
     }
 }
 
+// Shading as a launch of its own, one thread per pixel (a wave writes 256 contiguous bytes of
+// RGBA8), for cull_trace_kernel: at its three waves per SIMD the long dependent chains of
+// phong_light (normalise, pow, divide) are better hidden by a kernel that needs few registers.
+template <int PROJ>
+__global__ __launch_bounds__(256) void shade_kernel(const RenderParams p,
+                                                   const float* __restrict__ t_in,
+                                                   const int32_t* __restrict__ id_in,
+                                                   uint32_t pitch) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t lr = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.xres || lr >= p.local_rows) return;
+    const size_t src = (size_t)lr * pitch + x;
+    p.out[(size_t)lr * p.xres + x] = shade_pixel<PROJ>(p, x, image_row(p, lr), t_in[src], id_in[src]);
+}
+
 template __global__ void trace_kernel<MRT_PROJ_ORTHO, false>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_PERSP, false>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_ORTHO, true>(const RenderParams, float*, int32_t*, uint32_t);
@@ -966,5 +981,8 @@ template __global__ void prep_full_records<MRT_PROJ_ORTHO>(const RenderParams, f
 template __global__ void prep_full_records<MRT_PROJ_PERSP>(const RenderParams, float4*);
 template __global__ void cull_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void cull_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, float*, int32_t*, uint32_t);
+
+template __global__ void shade_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float*, const int32_t*, uint32_t);
+template __global__ void shade_kernel<MRT_PROJ_PERSP>(const RenderParams, const float*, const int32_t*, uint32_t);
 
 }  // namespace mrt
