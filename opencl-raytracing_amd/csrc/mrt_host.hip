@@ -23,10 +23,10 @@ __global__ void trace_kernel(const RenderParams p, float* t_out, int32_t* id_out
 template <int PROJ>
 __global__ void cull_trace_kernel(const RenderParams p, float* t_out, int32_t* id_out, uint32_t pitch);
 template <int PROJ>
-__global__ void full_trace_kernel(const RenderParams p, const float4* full_rec, float* t_out, int32_t* id_out,
-                                  uint32_t pitch);
+__global__ void full_trace_kernel(const RenderParams p, const float4* full_rec, const uint32_t* full_ids,
+                                  const uint32_t* class_counts, float* t_out, int32_t* id_out, uint32_t pitch);
 template <int PROJ>
-__global__ void prep_full_records(const RenderParams p, float4* rec);
+__global__ void prep_full_records(const RenderParams p, float4* rec, uint32_t* ids, uint32_t* counts);
 template <int PROJ>
 __global__ void shade_kernel(const RenderParams p, const float* t_in, const int32_t* id_in, uint32_t pitch);
 }  // namespace mrt
@@ -56,7 +56,11 @@ struct mrt_ctx {
     void* d_tri_circle = nullptr;
     size_t cap_sph_filter = 0, cap_tri_filter = 0, cap_tri_circle = 0;
     void* d_tri_exact = nullptr;
-    void* d_full_rec = nullptr;     // MRT_FLAG_FULL_TEST only: per-view records of full_trace_kernel
+    // MRT_FLAG_FULL_TEST only: per-view records of full_trace_kernel, grouped by hit sign, the
+    // triangle each record belongs to, and the two group sizes
+    void* d_full_rec = nullptr;
+    uint32_t* d_full_ids = nullptr;
+    uint32_t* d_full_counts = nullptr;
     size_t cap_full_rec = 0;
     void* d_sph = nullptr;
     void* d_sph_mat = nullptr;
@@ -529,10 +533,10 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     p.fuse_shade = (cull && !full) ? 0u : ((p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u);
     if ((ctx->flags & MRT_FLAG_FULL_TEST) && persp)
         hipLaunchKernelGGL((mrt::full_trace_kernel<MRT_PROJ_PERSP>), fgrid, tb, 0, stream, p,
-                           (const float4*)ctx->d_full_rec, ctx->d_t, ctx->d_id, pitch);
+                           (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, ctx->d_t, ctx->d_id, pitch);
     else if (ctx->flags & MRT_FLAG_FULL_TEST)
         hipLaunchKernelGGL((mrt::full_trace_kernel<MRT_PROJ_ORTHO>), fgrid, tb, 0, stream, p,
-                           (const float4*)ctx->d_full_rec, ctx->d_t, ctx->d_id, pitch);
+                           (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, ctx->d_t, ctx->d_id, pitch);
     else if (cull && persp)
         hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_PERSP>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
     else if (cull)
@@ -625,6 +629,8 @@ void mrt_destroy(mrt_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_dev(ctx->d_sph_filter); free_dev(ctx->d_tri_filter); free_dev(ctx->d_tri_circle); free_dev(ctx->d_tri_exact); free_dev(ctx->d_full_rec); free_dev(ctx->d_sph);
+    if (ctx->d_full_ids) (void)hipFree(ctx->d_full_ids);
+    if (ctx->d_full_counts) (void)hipFree(ctx->d_full_counts);
     free_dev(ctx->d_sph_mat); free_dev(ctx->d_mats); free_dev(ctx->d_lights);
     if (ctx->d_t) (void)hipFree(ctx->d_t);
     if (ctx->d_id) (void)hipFree(ctx->d_id);
@@ -680,21 +686,30 @@ static int rebuild_view(mrt_ctx* ctx) {
 
     if (ctx->flags & MRT_FLAG_FULL_TEST) {
         // Records of full_trace_kernel, made on the device so that they carry the device's own
-        // roundings; padded with zeros to whole LDS chunks (the kernel never tests the padding).
-        const size_t bytes = (size_t)round_up(s->n_tris ? s->n_tris : 1, mrt::kChunkTris) * 3 * sizeof(float4);
+        // roundings.  One chunk of slack: the kernel stages whole LDS chunks from wherever a sign
+        // group starts (it never tests what lies beyond the group).
+        const size_t n_rec = (size_t)round_up(s->n_tris ? s->n_tris : 1, mrt::kChunkTris) + mrt::kChunkTris;
+        const size_t bytes = n_rec * 3 * sizeof(float4);
         if (!ctx->d_full_rec || ctx->cap_full_rec != bytes) {
             free_dev(ctx->d_full_rec);
+            if (ctx->d_full_ids) { (void)hipFree(ctx->d_full_ids); ctx->d_full_ids = nullptr; }
             ctx->cap_full_rec = 0;
             HIP_TRY(ctx, hipMalloc(&ctx->d_full_rec, bytes));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_full_ids, n_rec * sizeof(uint32_t)));
             ctx->cap_full_rec = bytes;
         }
+        if (!ctx->d_full_counts) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_full_counts, 2 * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_full_rec, 0, bytes, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_full_ids, 0, n_rec * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_full_counts, 0, 2 * sizeof(uint32_t), ctx->stream));
         if (s->n_tris) {
             const dim3 g((s->n_tris + 255) / 256), b(256);
             if (s->projection == MRT_PROJ_PERSP)
-                hipLaunchKernelGGL(mrt::prep_full_records<MRT_PROJ_PERSP>, g, b, 0, ctx->stream, p, (float4*)ctx->d_full_rec);
+                hipLaunchKernelGGL(mrt::prep_full_records<MRT_PROJ_PERSP>, g, b, 0, ctx->stream, p,
+                                   (float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts);
             else
-                hipLaunchKernelGGL(mrt::prep_full_records<MRT_PROJ_ORTHO>, g, b, 0, ctx->stream, p, (float4*)ctx->d_full_rec);
+                hipLaunchKernelGGL(mrt::prep_full_records<MRT_PROJ_ORTHO>, g, b, 0, ctx->stream, p,
+                                   (float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts);
             HIP_TRY(ctx, hipGetLastError());
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -31,6 +31,7 @@
 #include "mrt_kernels.hpp"
 
 #include <float.h>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -718,10 +719,22 @@ __device__ __forceinline__ float tri_verdict(float det, float nb, float ng, floa
 }  // namespace
 
 // Per-view triangle records of full_trace_kernel, by the same arithmetic as
-// tri_intersect: pinhole (s1 | s2 | a - eye | Nt), orthographic (s1 | s2 | a |
-// minors(s2, d)) with s1 = a - b, s2 = a - c (kernel.cl:204-206).
+// tri_intersect: pinhole (s1 | s2 | a - eye | Nt, zero band), orthographic
+// (s1 | s2 | a | minors(s2, d)) with s1 = a - b, s2 = a - c (kernel.cl:204-206).
+//
+// A hit needs t = Nt/det > 0, so the sign det has at a hit is a property of the
+// triangle: the sign of Nt for the pinhole camera (Nt does not depend on the
+// pixel), of det for the orthographic one (det does not).  The records are
+// written in two groups -- sign +1 from the front of the buffer, sign -1 from
+// its end (at n_tri - 1 downwards), counts[0] and counts[1] of them -- so that
+// the kernel runs each group through straight-line code made for that sign.
+// Triangles with a zero or NaN sign can never be accepted (t would be 0, NaN or
+// infinite) and get no record.  The order inside a group is whatever the
+// atomics give; the kernel breaks ties in t by object id, which is what
+// processing in object order with a strict "<" amounts to (kernel.cl:326).
 template <int PROJ>
-__global__ void prep_full_records(const RenderParams p, float4* __restrict__ rec) {
+__global__ void prep_full_records(const RenderParams p, float4* __restrict__ rec, uint32_t* __restrict__ ids,
+                                  uint32_t* __restrict__ counts) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= p.n_tri) return;
     const float4 va = p.tri_exact[(size_t)k * 3 + 0];
@@ -730,30 +743,46 @@ __global__ void prep_full_records(const RenderParams p, float4* __restrict__ rec
     const F3 a = mk3(va.x, va.y, va.z);
     const F3 s1 = sub3(a, mk3(vb.x, vb.y, vb.z));
     const F3 s2 = sub3(a, mk3(vc.x, vc.y, vc.z));
+    float4 r0, r1, r2;
+    float sign_src;
     if (PROJ == MRT_PROJ_PERSP) {
         const F3 sol = sub3(a, mk3(p.eye[0], p.eye[1], p.eye[2]));
         const float nt = det3(s1, s2, sol);
-        rec[(size_t)k * 3 + 0] = make_float4(s1.x, s1.y, s1.z, s2.x);
-        rec[(size_t)k * 3 + 1] = make_float4(s2.y, s2.z, sol.x, sol.y);
         // |det| <= 6 max|s1| max|s2| max|d| for every pixel; 2^-100 of that is the zero band
         const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(s1.x), __builtin_fabsf(s1.y)), __builtin_fabsf(s1.z));
         const float m2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(s2.x), __builtin_fabsf(s2.y)), __builtin_fabsf(s2.z));
         const float band = 6.1f * m1 * m2 * p.ray_absmax * 0x1p-100f;
-        rec[(size_t)k * 3 + 2] = make_float4(sol.z, nt, band == band ? band : __builtin_inff(), 0.0f);
+        r0 = make_float4(s1.x, s1.y, s1.z, s2.x);
+        r1 = make_float4(s2.y, s2.z, sol.x, sol.y);
+        r2 = make_float4(sol.z, nt, band == band ? band : __builtin_inff(), 0.0f);
+        sign_src = nt;
     } else {
         const M3 m = minors(s2, mk3(-p.w[0], -p.w[1], -p.w[2]));
-        rec[(size_t)k * 3 + 0] = make_float4(s1.x, s1.y, s1.z, s2.x);
-        rec[(size_t)k * 3 + 1] = make_float4(s2.y, s2.z, a.x, a.y);
-        rec[(size_t)k * 3 + 2] = make_float4(a.z, m.m0, m.m1, m.m2);
+        r0 = make_float4(s1.x, s1.y, s1.z, s2.x);
+        r1 = make_float4(s2.y, s2.z, a.x, a.y);
+        r2 = make_float4(a.z, m.m0, m.m1, m.m2);
+        sign_src = expand(s1, m);        // det, as the kernel computes it
     }
+    uint32_t slot;
+    if (sign_src > 0.0f) slot = atomicAdd(&counts[0], 1u);
+    else if (sign_src < 0.0f) slot = p.n_tri - 1u - atomicAdd(&counts[1], 1u);
+    else return;
+    rec[(size_t)slot * 3 + 0] = r0;
+    rec[(size_t)slot * 3 + 1] = r1;
+    rec[(size_t)slot * 3 + 2] = r2;
+    ids[slot] = k;
 }
 
 template <int PROJ>
 __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderParams p,
                                                                   const float4* __restrict__ full_rec,
+                                                                  const uint32_t* __restrict__ full_ids,
+                                                                  const uint32_t* __restrict__ class_counts,
                                                                   float* __restrict__ t_out,
                                                                   int32_t* __restrict__ id_out, uint32_t pitch) {
     __shared__ float4 s_rec[kChunkFloat4];
+    __shared__ uint32_t s_ids[kChunkTris];
+    static_assert(kChunkTris == kBlockThreads, "one triangle id per thread when a chunk is staged");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -837,104 +866,82 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
         }
     }
 
-    // ---- triangles: object ids n_sph .. n_sph+n_tri-1 ----
-    for (uint32_t base = 0; base < p.n_tri; base += kChunkTris) {
-        __syncthreads();
-        stage_chunk(s_rec, full_rec + (size_t)base * 3, tid);     // padded to whole chunks
-        __syncthreads();
-        if (!wave_active) continue;
-        const uint32_t count = (p.n_tri - base) < (uint32_t)kChunkTris ? (p.n_tri - base) : (uint32_t)kChunkTris;
-        for (uint32_t g = 0; g < count; ++g) {
-            const float4 q0 = s_rec[g * 3 + 0];
-            const float4 q1 = s_rec[g * 3 + 1];
-            const float4 q2 = s_rec[g * 3 + 2];
-            const F3 s1 = mk3(q0.x, q0.y, q0.z);
-            const F3 s2 = mk3(q0.w, q1.x, q1.y);
-            const F3 third = mk3(q1.z, q1.w, q2.x);     // a - eye (pinhole) or a (orthographic)
-            // The sign of det at a valid hit, the same for the whole wave: +1, -1, or 0 when
-            // no pixel can be accepted (Nt or det is zero or NaN: t is 0, NaN or infinite).
-            bool cand;
-            if (PROJ == MRT_PROJ_PERSP) {
-                const float nt = q2.y, band = q2.z;
-                const float nt_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(nt)));
-                if (nt_u > 0.0f) {
-                    float acc = -__builtin_inff();
+    // ---- triangles: object ids n_sph .. n_sph+n_tri-1, one sign group after the other ----
+    auto sign_group = [&](auto pos_tag, uint32_t first, uint32_t n) {
+        constexpr bool POS = decltype(pos_tag)::value;
+        for (uint32_t base = 0; base < n; base += kChunkTris) {
+            __syncthreads();
+            stage_chunk(s_rec, full_rec + (size_t)(first + base) * 3, tid);   // the buffer has a chunk of slack
+            s_ids[tid] = full_ids[first + base + tid];
+            __syncthreads();
+            if (!wave_active) continue;
+            const uint32_t count = (n - base) < (uint32_t)kChunkTris ? (n - base) : (uint32_t)kChunkTris;
+            for (uint32_t g = 0; g < count; ++g) {
+                const float4 q0 = s_rec[g * 3 + 0];
+                const float4 q1 = s_rec[g * 3 + 1];
+                const float4 q2 = s_rec[g * 3 + 2];
+                const F3 s1 = mk3(q0.x, q0.y, q0.z);
+                const F3 s2 = mk3(q0.w, q1.x, q1.y);
+                const F3 third = mk3(q1.z, q1.w, q2.x);     // a - eye (pinhole) or a (orthographic)
+                float acc = POS ? -__builtin_inff() : __builtin_inff();
+                float band;
+                if (PROJ == MRT_PROJ_PERSP) {
+                    const float nt = q2.y;
+                    band = q2.z;
 #pragma unroll
                     for (int s = 0; s < kFullSlots; ++s) {
                         const M3 m = minors(s2, ray[s]);
                         const float det = expand(s1, m);
                         const float nb = expand(third, m);
                         const float ng = expand(s1, minors(third, ray[s]));
-                        acc = __builtin_fmaxf(acc, tri_verdict<true>(det, nb, ng, nt, bound_up[s], rel_up));
+                        const float v = tri_verdict<POS>(det, nb, ng, nt, bound_up[s], rel_up);
+                        acc = POS ? __builtin_fmaxf(acc, v) : __builtin_fminf(acc, v);
                     }
-                    cand = acc >= -band;
-                } else if (nt_u < 0.0f) {
-                    float acc = __builtin_inff();
-#pragma unroll
-                    for (int s = 0; s < kFullSlots; ++s) {
-                        const M3 m = minors(s2, ray[s]);
-                        const float det = expand(s1, m);
-                        const float nb = expand(third, m);
-                        const float ng = expand(s1, minors(third, ray[s]));
-                        acc = __builtin_fminf(acc, tri_verdict<false>(det, nb, ng, nt, bound_up[s], rel_up));
-                    }
-                    cand = acc <= band;
                 } else {
-                    continue;
-                }
-            } else {
-                M3 m;
-                m.m0 = q2.y; m.m1 = q2.z; m.m2 = q2.w;
-                const float det = expand(s1, m);
-                const float det_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(det)));
-                const float band = __builtin_fabsf(det) * 0x1p-100f;
-                if (det_u > 0.0f) {
-                    float acc = -__builtin_inff();
+                    M3 m;
+                    m.m0 = q2.y; m.m1 = q2.z; m.m2 = q2.w;
+                    const float det = expand(s1, m);
+                    band = __builtin_fabsf(det) * 0x1p-100f;
 #pragma unroll
                     for (int s = 0; s < kFullSlots; ++s) {
                         const F3 sol = sub3(third, ray[s]);
                         const float nb = expand(sol, m);
                         const float ng = expand(s1, minors(sol, shared_part));
                         const float nt = expand(s1, minors(s2, sol));
-                        acc = __builtin_fmaxf(acc, tri_verdict<true>(det, nb, ng, nt, bound_up[s], rel_up));
+                        const float v = tri_verdict<POS>(det, nb, ng, nt, bound_up[s], rel_up);
+                        acc = POS ? __builtin_fmaxf(acc, v) : __builtin_fminf(acc, v);
                     }
-                    cand = acc >= -band;
-                } else if (det_u < 0.0f) {
-                    float acc = __builtin_inff();
+                }
+                const bool cand = POS ? (acc >= -band) : (acc <= band);
+                if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+                if (cand) {
+                    const uint32_t ti = __builtin_amdgcn_readfirstlane(s_ids[g]);
+                    const float4 va = p.tri_exact[(size_t)ti * 3 + 0];
+                    const float4 vb = p.tri_exact[(size_t)ti * 3 + 1];
+                    const float4 vc = p.tri_exact[(size_t)ti * 3 + 2];
+                    const F3 A = mk3(va.x, va.y, va.z), B = mk3(vb.x, vb.y, vb.z), C = mk3(vc.x, vc.y, vc.z);
+                    const int32_t obj_id = (int32_t)(p.n_sph + ti);
 #pragma unroll
                     for (int s = 0; s < kFullSlots; ++s) {
-                        const F3 sol = sub3(third, ray[s]);
-                        const float nb = expand(sol, m);
-                        const float ng = expand(s1, minors(sol, shared_part));
-                        const float nt = expand(s1, minors(s2, sol));
-                        acc = __builtin_fminf(acc, tri_verdict<false>(det, nb, ng, nt, bound_up[s], rel_up));
-                    }
-                    cand = acc <= band;
-                } else {
-                    continue;
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
-            if (cand) {
-                const uint32_t ti = base + g;
-                const float4 va = p.tri_exact[(size_t)ti * 3 + 0];
-                const float4 vb = p.tri_exact[(size_t)ti * 3 + 1];
-                const float4 vc = p.tri_exact[(size_t)ti * 3 + 2];
-                const F3 A = mk3(va.x, va.y, va.z), B = mk3(vb.x, vb.y, vb.z), C = mk3(vc.x, vc.y, vc.z);
-#pragma unroll
-                for (int s = 0; s < kFullSlots; ++s) {
-                    const F3 o = (PROJ == MRT_PROJ_PERSP) ? shared_part : ray[s];
-                    const F3 d = (PROJ == MRT_PROJ_PERSP) ? ray[s] : shared_part;
-                    float t;
-                    if (tri_exact(A, B, C, o, d, best_t[s], 0.0f, t) && t > 0.0f && t < best_t[s]) {
-                        best_t[s] = t;
-                        bound_up[s] = t * 1.00001f;
-                        best_id[s] = (int32_t)(p.n_sph + ti);
+                        const F3 o = (PROJ == MRT_PROJ_PERSP) ? shared_part : ray[s];
+                        const F3 d = (PROJ == MRT_PROJ_PERSP) ? ray[s] : shared_part;
+                        float t;
+                        // The groups are not in object order: equal t goes to the lower id, which
+                        // is what the reference's strict "<" in object order gives (kernel.cl:326).
+                        if (tri_exact(A, B, C, o, d, best_t[s], 0.0f, t) && t > 0.0f &&
+                            (t < best_t[s] || (t == best_t[s] && obj_id < best_id[s]))) {
+                            best_t[s] = t;
+                            bound_up[s] = t * 1.00001f;
+                            best_id[s] = obj_id;
+                        }
                     }
                 }
             }
         }
-    }
+    };
+    const uint32_t n_pos = class_counts[0], n_neg = class_counts[1];
+    sign_group(std::true_type{}, 0u, n_pos);
+    sign_group(std::false_type{}, p.n_tri - n_neg, n_neg);
 
     if (wave_active) {
 #pragma unroll
@@ -975,10 +982,10 @@ template __global__ void trace_kernel<MRT_PROJ_ORTHO, false>(const RenderParams,
 template __global__ void trace_kernel<MRT_PROJ_PERSP, false>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_ORTHO, true>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_PERSP, true>(const RenderParams, float*, int32_t*, uint32_t);
-template __global__ void full_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float4*, float*, int32_t*, uint32_t);
-template __global__ void full_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, const float4*, float*, int32_t*, uint32_t);
-template __global__ void prep_full_records<MRT_PROJ_ORTHO>(const RenderParams, float4*);
-template __global__ void prep_full_records<MRT_PROJ_PERSP>(const RenderParams, float4*);
+template __global__ void full_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, float*, int32_t*, uint32_t);
+template __global__ void full_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, float*, int32_t*, uint32_t);
+template __global__ void prep_full_records<MRT_PROJ_ORTHO>(const RenderParams, float4*, uint32_t*, uint32_t*);
+template __global__ void prep_full_records<MRT_PROJ_PERSP>(const RenderParams, float4*, uint32_t*, uint32_t*);
 template __global__ void cull_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void cull_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, float*, int32_t*, uint32_t);
 
