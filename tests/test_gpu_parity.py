@@ -329,6 +329,36 @@ def test_non_finite_and_odd_inputs(mrt, oracle):
             check(r["rgba"], o["rgba"], o["ids"])
 
 
+def test_equal_t_goes_to_the_lower_object_id(mrt, oracle):
+    """Coincident primitives give equal t; the reference keeps the first in object order (strict
+    '<', kernel.cl:326,344).  The full-test kernel evaluates triangles grouped by hit sign, in an
+    order its atomics decide, so this must hold by its id tie-break -- on every run."""
+    rng = np.random.default_rng(77)
+    base = rng.uniform(-1, 1, (40, 9)) * 0.8 + np.tile([0, 0, -3.0], 3)
+    flipped = base[:, [0, 1, 2, 6, 7, 8, 3, 4, 5]]                 # same triangles, opposite winding
+    tri = np.concatenate([base, flipped, base[::-1], flipped[5:25]], axis=0).T
+    n_tri = tri.shape[1]
+    sph = np.array([[0.3, 0.2, -2.0, 0.5], [0.3, 0.2, -2.0, 0.5], [-0.6, -0.4, -2.5, 0.4],
+                    [-0.6, -0.4, -2.5, 0.4]]).T
+    for proj in (mrt.PROJ_PERSP, mrt.PROJ_ORTHO):
+        sc = mrt.Scene(eye=[0, 0, 0], u=[1, 0, 0], v=[0, 1, 0], w=[0, 0, 1], xres=160, yres=120, left=-1.3,
+                       right=1.3, top=1.0, bottom=-1.0, projection=proj, focal=1.0, shader=mrt.SHADER_FLAT,
+                       background=(0, 0, 0), sph=sph, sph_mat=[0, 1, 2, 3], tri=tri,
+                       tri_mat=np.arange(n_tri) % 7, mat=[np.linspace(0.1, 1, 7), np.linspace(1, 0.1, 7),
+                                                          np.full(7, 0.5), np.full(7, 4.0)])
+        o = oracle.render(sc)
+        assert len(np.unique(o["ids"])) > 20
+        for flags in (mrt.FLAG_FULL_TEST, 0, mrt.FLAG_SCREEN_CULL, mrt.FLAG_NO_PREFILTER):
+            for _ in range(4 if flags == mrt.FLAG_FULL_TEST else 1):
+                ctx = mrt.Context(device=0, flags=flags)
+                try:
+                    r = gpu_render(ctx, sc)
+                finally:
+                    ctx.close()
+                assert_same_hits(r, o)
+                assert np.array_equal(r["rgba"], o["rgba"])
+
+
 def test_camera_inside_and_behind_geometry(gpu_ctx, mrt, oracle):
     """Primitives that straddle or lie behind the eye plane, a sphere containing the eye, huge and
     tiny primitives: the prefilter must stay a superset wherever its projection is unbounded."""
