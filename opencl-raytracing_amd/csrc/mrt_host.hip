@@ -4,7 +4,7 @@
 // context, compiled kernel.cl, allocated buffers, copied in, launched with a
 // fixed 160000 work-items and copied out (CLHelpers.hpp:76-322), a context
 // here owns one stream and its device buffers for its whole life, the scene is
-// uploaded once (mrt_set_scene) and a frame is two kernel launches.
+// uploaded once (mrt_set_scene) and a frame is one kernel launch.
 #include "mrt.h"
 #include "mrt_kernels.hpp"
 
