@@ -490,7 +490,7 @@ int ensure_out(mrt_ctx* ctx, size_t elems) {
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
-// Enqueue both kernels for this rank's rows on `stream`.
+// Enqueue the frame (one launch, two for the tile cull) for this rank's rows on `stream`.
 int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world, uint32_t* dev_out,
                  hipStream_t stream, bool timed) {
     RenderParams p = ctx->params;
