@@ -203,50 +203,6 @@ __device__ __forceinline__ void exact_pass(const RenderParams& p, uint32_t mask,
     }
 }
 
-// As exact_pass, for a kernel that keeps the closest hit of its 16 pixels in registers and the
-// uv components of its four columns and four rows too: nothing in the loop touches memory.
-// Slot s = 4*row + column is visited when some lane of the wave has its bit set.
-template <int PROJ, bool TRI>
-__device__ __forceinline__ void exact_slots(const RenderParams& p, uint32_t mask, uint32_t prim,
-                                            const float (&ux)[kLanePx], const float (&uy)[kLanePx],
-                                            float (&best_t)[kLanePx * kLanePx], int32_t (&best_id)[kLanePx * kLanePx],
-                                            unsigned long long& n_exact) {
-    const float t_lower = 0.0f;   // scene::intersect, gfxraytrace.hpp:812
-    F3 A, B, C;
-    float radius = 0.0f;
-    if (TRI) {
-        const float4 va = p.tri_exact[(size_t)prim * 3 + 0];
-        const float4 vb = p.tri_exact[(size_t)prim * 3 + 1];
-        const float4 vc = p.tri_exact[(size_t)prim * 3 + 2];
-        A = mk3(va.x, va.y, va.z); B = mk3(vb.x, vb.y, vb.z); C = mk3(vc.x, vc.y, vc.z);
-    } else {
-        const float4 sp = p.sph[prim];
-        A = mk3(sp.x, sp.y, sp.z); B = A; C = A;
-        radius = sp.w;
-    }
-    const int32_t obj_id = (int32_t)(TRI ? p.n_sph + prim : prim);   // spheres first, gfxraytrace.hpp:701-714
-#pragma unroll
-    for (int s = 0; s < kLanePx * kLanePx; ++s) {
-        const bool mine = (mask >> s) & 1u;
-        if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
-        if (mine) {
-            F3 o, d;
-            pixel_ray<PROJ>(p, ux[s & 3], uy[s >> 2], o, d);
-            float t;
-            bool hit, two;
-            // tri_intersect / circle_intersect against the current bound (kernel.cl:324,341),
-            // then the loop's strict acceptance (:326,:344).
-            if (TRI) hit = tri_exact(A, B, C, o, d, best_t[s], t_lower, t);
-            else hit = sphere_exact(A, radius, o, d, best_t[s], t_lower, t, two);
-            if (hit && t > t_lower && t < best_t[s]) {
-                best_t[s] = t;
-                best_id[s] = obj_id;
-            }
-            ++n_exact;
-        }
-    }
-}
-
 }  // namespace
 
 template <int PROJ, bool BLOCK_REJECT>
@@ -498,52 +454,140 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
 // ---------------------------------------------------------------------------
 // Opt-in screen-space culling (MRT_FLAG_SCREEN_CULL); never the default path.
 //
-// Same tiles, same records, same exact pass as trace_kernel, but the first
-// rejection is done per wave tile with the lanes spread over PRIMITIVES: lane l
-// tests primitive base+l against the wave's whole 32x32 tile (nearest point of
-// the tile to the bounding circle / ellipse, and each edge function at its best
-// tile corner), a ballot gives the survivors, and only those are then tested
-// per 4x4 lane block, per pixel and exactly, in increasing object order.
-// Needs a tile's 32 rows to be consecutive image rows (band height a multiple
-// of 32); the host falls back to trace_kernel otherwise.
+// Same tiles and records as trace_kernel, but the first rejection is done per
+// wave tile with the lanes spread over PRIMITIVES: lane l tests primitive
+// base + l against the wave's whole 32x32 tile (nearest point of the tile to the
+// bounding circle / ellipse, and each edge function at its best tile corner) and
+// a ballot gives the survivors.  A survivor is then tested per 4x4 lane block
+// and per pixel with the same records; the pixels that pass are written, as a
+// compact list, to LDS and the reference arithmetic runs over that list 64
+// pixels at a time, whichever lane they belong to -- so a triangle that covers
+// 40 pixels costs one pass with 40 lanes busy instead of up to 16 passes with
+// two or three.  The closest hit of the tile's 1024 pixels lives in LDS as a
+// 64-bit key (t bits << 32 | object id) updated with an atomic minimum: hits
+// have t > 0, so the keys order like (t, id), and the smallest key is the hit
+// the reference's loop keeps -- the smallest t, the lowest id among equals
+// (strict "<" in object order, kernel.cl:326,344) -- in whatever order the
+// pairs are evaluated.  Needs a tile's 32 rows to be consecutive image rows
+// (band height a multiple of 32); the host falls back to trace_kernel otherwise.
 // ---------------------------------------------------------------------------
+constexpr unsigned long long kNoHitKey = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;   // (FLT_MAX, -1)
+
+namespace {
+
+// The reference arithmetic for one primitive over the listed pixels of the tile.
+template <int PROJ, bool TRI>
+__device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim, uint32_t total, int lane,
+                                           const uint16_t* __restrict__ list, const float* __restrict__ tile_ux,
+                                           const float* __restrict__ tile_uy, unsigned long long* __restrict__ keys,
+                                           unsigned long long& n_exact) {
+    F3 A, B, C;
+    float radius = 0.0f;
+    if (TRI) {
+        const float4 va = p.tri_exact[(size_t)prim * 3 + 0];
+        const float4 vb = p.tri_exact[(size_t)prim * 3 + 1];
+        const float4 vc = p.tri_exact[(size_t)prim * 3 + 2];
+        A = mk3(va.x, va.y, va.z); B = mk3(vb.x, vb.y, vb.z); C = mk3(vc.x, vc.y, vc.z);
+    } else {
+        const float4 sp = p.sph[prim];
+        A = mk3(sp.x, sp.y, sp.z); B = A; C = A;
+        radius = sp.w;
+    }
+    const uint32_t obj_id = TRI ? p.n_sph + prim : prim;          // spheres first, gfxraytrace.hpp:701-714
+    for (uint32_t b = 0; b < total; b += 64) {
+        const uint32_t idx = b + (uint32_t)lane;
+        if (idx < total) {
+            const uint32_t px = list[idx];
+            F3 o, d;
+            pixel_ray<PROJ>(p, tile_ux[px & 31u], tile_uy[px >> 5], o, d);
+            float t;
+            bool hit, two;
+            // Bounds of scene::intersect (gfxraytrace.hpp:812-813); the running bound of the
+            // reference's loop only rejects what the minimum below rejects too.
+            if (TRI) hit = tri_exact(A, B, C, o, d, FLT_MAX, 0.0f, t);
+            else hit = sphere_exact(A, radius, o, d, FLT_MAX, 0.0f, t, two);
+            if (hit && t > 0.0f && t < FLT_MAX)
+                atomicMin(&keys[px], ((unsigned long long)__float_as_uint(t) << 32) | obj_id);
+            ++n_exact;
+        }
+    }
+}
+
+}  // namespace
+
 template <int PROJ>
 __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderParams p,
                                                                   float* __restrict__ t_out,
                                                                   int32_t* __restrict__ id_out,
                                                                   uint32_t pitch) {
+    constexpr int kWaves = kBlockThreads / 64, kTilePx = kWaveTile * kWaveTile;
+    __shared__ unsigned long long s_key[kWaves][kTilePx];     // closest hit per pixel of the wave's tile
+    __shared__ uint16_t s_list[kWaves][kTilePx];              // pixels one primitive still has to be tested on
+    __shared__ float s_ux[kWaves][kWaveTile], s_uy[kWaves][kWaveTile];
+    __shared__ uint32_t s_count[kWaves];
+
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const uint32_t wave_x0 = blockIdx.x * kBlockTileX + (wave & 1) * kWaveTile;
     const uint32_t wave_lr0 = blockIdx.y * kBlockTileY + (wave >> 1) * kWaveTile;
-    if (!((wave_x0 < p.xres) && (wave_lr0 < p.local_rows))) return;   // no barriers in this kernel
-    const uint32_t x0 = wave_x0 + (lane & 7) * kLanePx;
-    const uint32_t lr0 = wave_lr0 + (lane >> 3) * kLanePx;
+    if (!((wave_x0 < p.xres) && (wave_lr0 < p.local_rows))) return;   // no block-level barriers in this kernel
+    const uint32_t bx = (lane & 7) * kLanePx, by = (lane >> 3) * kLanePx;   // this lane's block inside the tile
+    const uint32_t x0 = wave_x0 + bx;
+    const uint32_t lr0 = wave_lr0 + by;
+    unsigned long long* keys = s_key[wave];
+    uint16_t* list = s_list[wave];
+    float* tile_ux = s_ux[wave];
+    float* tile_uy = s_uy[wave];
 
     // Tile and lane-block origins in image pixel coordinates.
     const float txf = (float)wave_x0;
     const float tyf = (float)image_row(p, wave_lr0);
     const float xf = (float)x0;
-    const float yf0 = tyf + (float)((lane >> 3) * kLanePx);
+    const float yf0 = tyf + (float)by;
     const float tile_span = (float)(kWaveTile - 1);
 
-    // Closest hit so far (t = FLT_MAX, gfxraytrace.hpp:813) and the uv components of this lane's
-    // columns and rows (gfxraytrace.hpp:850-852: the pixel grid is (x + 1, y + 1)) stay in registers.
-    float best_t[kLanePx * kLanePx], ux[kLanePx], uy[kLanePx];
-    int32_t best_id[kLanePx * kLanePx];
+    // uv of the tile's 32 columns and 32 rows (gfxraytrace.hpp:850-852: the pixel grid is
+    // (x + 1, y + 1)); rows past the end of this rank's rows repeat the last one, as everywhere.
     {
         const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
-#pragma unroll
-        for (int k = 0; k < kLanePx; ++k) {
-            const uint32_t lr = lr0 + k;
-            ux[k] = uv_component(p.left, p.right, (float)(x0 + k) + 1.0f, p.xres_f);
-            uy[k] = uv_component(p.bottom, p.top, (float)image_row(p, lr < last_row ? lr : last_row) + 1.0f, p.yres_f);
+        const uint32_t k = lane & 31;
+        if (lane < 32) {
+            tile_ux[k] = uv_component(p.left, p.right, (float)(wave_x0 + k) + 1.0f, p.xres_f);
+        } else {
+            const uint32_t lr = wave_lr0 + k;
+            tile_uy[k] = uv_component(p.bottom, p.top, (float)image_row(p, lr < last_row ? lr : last_row) + 1.0f, p.yres_f);
         }
 #pragma unroll
-        for (int s = 0; s < kLanePx * kLanePx; ++s) { best_t[s] = FLT_MAX; best_id[s] = -1; }
+        for (int k2 = 0; k2 < kTilePx / 64; ++k2) keys[k2 * 64 + lane] = kNoHitKey;
+        if (lane == 0) s_count[wave] = 0;
     }
+    // LDS operations of one wave complete in order and no other wave touches these arrays, so
+    // a wave-level fence is all the synchronisation this kernel needs.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     unsigned long long n_exact = 0;
+
+    // Writes the pixels of `mask` (bit r = row r/4, column r%4 of this lane's block) to the
+    // list; returns how many pixels the whole wave listed.
+    auto list_pixels = [&](uint32_t mask) -> uint32_t {
+        const uint32_t c = (uint32_t)__builtin_popcount(mask);
+        uint32_t at = 0;
+        if (c) at = atomicAdd(&s_count[wave], c);
+        while (mask) {
+            const uint32_t r = (uint32_t)__builtin_ctz(mask);
+            mask &= mask - 1;
+            list[at++] = (uint16_t)((by + (r >> 2)) * kWaveTile + bx + (r & 3u));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t total = s_count[wave];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) s_count[wave] = 0;
+        return (uint32_t)__builtin_amdgcn_readfirstlane(total);
+    };
 
     // ---- spheres ----
     for (uint32_t base = 0; base < p.n_sph; base += 64) {
@@ -559,18 +603,21 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
             const uint32_t si = base + (uint32_t)__builtin_ctzll(live);
             live &= live - 1;
             const float4 f = p.sph_filter[si];
+            const float fx = in_vgpr(f.x), fz = in_vgpr(f.z);
             uint32_t mask = 0;
-            float dup = __builtin_fmaf(xf, f.x, f.y);
+            float dup = __builtin_fmaf(xf, fx, f.y);
 #pragma unroll
             for (int i = 0; i < kLanePx; ++i) {
 #pragma unroll
                 for (int j = 0; j < kLanePx; ++j) {
-                    const float dvp = __builtin_fmaf(yf0 + (float)j, f.z, f.w);
+                    const float dvp = __builtin_fmaf(yf0 + (float)j, fz, f.w);
                     if (__builtin_fmaf(dup, dup, __builtin_fmaf(dvp, dvp, -1.0f)) <= 0.0f) mask |= 1u << (j * kLanePx + i);
                 }
-                dup += f.x;
+                dup += fx;
             }
-            exact_slots<PROJ, false>(p, mask, si, ux, uy, best_t, best_id, n_exact);
+            if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
+            const uint32_t total = list_pixels(mask);
+            exact_list<PROJ, false>(p, si, total, lane, list, tile_ux, tile_uy, keys, n_exact);
         }
     }
 
@@ -628,20 +675,29 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
                 }
             }
             if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
-            exact_slots<PROJ, true>(p, mask, ti, ux, uy, best_t, best_id, n_exact);
+            const uint32_t total = list_pixels(mask);
+            exact_list<PROJ, true>(p, ti, total, lane, list, tile_ux, tile_uy, keys, n_exact);
         }
     }
 
+    // The atomics above are complete before this wave reads the keys back.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int j = 0; j < kLanePx; ++j) {
         const size_t off = (size_t)(lr0 + j) * pitch + x0;
+        unsigned long long k4[kLanePx];
+#pragma unroll
+        for (int i = 0; i < kLanePx; ++i) k4[i] = keys[(by + j) * kWaveTile + bx + i];
         int4 iv;
         float4 tv;
-        iv.x = best_id[j * 4 + 0]; iv.y = best_id[j * 4 + 1]; iv.z = best_id[j * 4 + 2]; iv.w = best_id[j * 4 + 3];
-        tv.x = iv.x < 0 ? -1.0f : best_t[j * 4 + 0];          // intersect.t_ of a miss, kernel.cl:363
-        tv.y = iv.y < 0 ? -1.0f : best_t[j * 4 + 1];
-        tv.z = iv.z < 0 ? -1.0f : best_t[j * 4 + 2];
-        tv.w = iv.w < 0 ? -1.0f : best_t[j * 4 + 3];
+        iv.x = (int32_t)(uint32_t)k4[0]; iv.y = (int32_t)(uint32_t)k4[1];
+        iv.z = (int32_t)(uint32_t)k4[2]; iv.w = (int32_t)(uint32_t)k4[3];
+        tv.x = iv.x < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[0] >> 32));      // intersect.t_ of a miss, kernel.cl:363
+        tv.y = iv.y < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[1] >> 32));
+        tv.z = iv.z < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[2] >> 32));
+        tv.w = iv.w < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[3] >> 32));
         *reinterpret_cast<float4*>(t_out + off) = tv;
         *reinterpret_cast<int4*>(id_out + off) = iv;       // shade_kernel takes it from here
     }
