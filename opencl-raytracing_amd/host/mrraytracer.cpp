@@ -11,6 +11,7 @@
 #include "mrt.h"
 
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -73,6 +74,9 @@ int main(int argc, char** argv) {
         return -1;
     }
     const std::string input_path = argv[1], output_path = argv[2];
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    const auto t_start = clk::now();
 
     mrt_loaded_scene* loaded = nullptr;
     char err[512];
@@ -81,6 +85,7 @@ int main(int argc, char** argv) {
         return 1;
     }
     const mrt_scene* scene = mrt_scene_view(loaded);
+    const double load_ms = ms_since(t_start);
     print_scene(*scene, *mrt_scene_info_view(loaded));
 
     std::cout << "raytracing..." << std::flush;
@@ -91,8 +96,10 @@ int main(int argc, char** argv) {
     const size_t n_bytes = static_cast<size_t>(scene->xres) * scene->yres * 4;
     mrt_stats stats;
     void* pinned = nullptr;
+    const auto t_create = clk::now();
     int rc = mrt_create(&cfg, &ctx);
     if (rc == MRT_OK) rc = mrt_host_alloc(n_bytes, &pinned);
+    const double create_ms = ms_since(t_create);       // HIP start-up, stream, page-locked frame buffer
     uint8_t* pixels = static_cast<uint8_t*>(pinned);
     if (rc == MRT_OK) rc = mrt_set_scene(ctx, scene);
     if (rc == MRT_OK) rc = mrt_render_rgba8(ctx, pixels, &stats);
@@ -106,6 +113,7 @@ int main(int argc, char** argv) {
     std::cout << "done" << std::endl;
 
     std::cout << "writing " << output_path << "..." << std::flush;
+    const auto t_png = clk::now();
     if (mrt_write_png_rgb(output_path.c_str(), pixels, scene->xres, scene->yres) != MRT_OK) {
         std::cerr << std::endl << "error: could not write PNG" << std::endl;
         mrt_host_free(pinned);
@@ -114,14 +122,16 @@ int main(int argc, char** argv) {
         return 1;
     }
     std::cout << "done" << std::endl << std::endl;
+    const double png_ms = ms_since(t_png);
 
     const char* want = std::getenv("MRT_STATS");
     if (want && want[0] == '1') {
         std::fprintf(stderr,
-                     "{\"rays\": %llu, \"prim_tests\": %llu, \"upload_ms\": %.4f, \"trace_ms\": %.4f, "
-                     "\"shade_ms\": %.4f, \"download_ms\": %.4f, \"mrays_per_s\": %.2f}\n",
-                     (unsigned long long)stats.rays, (unsigned long long)stats.prim_tests, stats.upload_ms,
-                     stats.trace_ms, stats.shade_ms, stats.download_ms,
+                     "{\"rays\": %llu, \"prim_tests\": %llu, \"load_ms\": %.3f, \"create_ms\": %.3f, "
+                     "\"upload_ms\": %.4f, \"trace_ms\": %.4f, \"shade_ms\": %.4f, \"download_ms\": %.4f, "
+                     "\"png_ms\": %.3f, \"total_ms\": %.3f, \"mrays_per_s\": %.2f}\n",
+                     (unsigned long long)stats.rays, (unsigned long long)stats.prim_tests, load_ms, create_ms,
+                     stats.upload_ms, stats.trace_ms, stats.shade_ms, stats.download_ms, png_ms, ms_since(t_start),
                      stats.kernel_ms > 0 ? stats.rays / stats.kernel_ms * 1e-3 : 0.0);
     }
     mrt_host_free(pinned);
