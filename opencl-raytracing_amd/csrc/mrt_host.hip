@@ -19,7 +19,8 @@
 
 namespace mrt {
 template <int PROJ, bool BLOCK_REJECT>
-__global__ void trace_kernel(const RenderParams p, float* t_out, int32_t* id_out, uint32_t pitch);
+__global__ void trace_kernel(const RenderParams p, unsigned long long* key_plane, float* t_out, int32_t* id_out,
+                             uint32_t pitch);
 template <int PROJ>
 __global__ void cull_trace_kernel(const RenderParams p, float* t_out, int32_t* id_out, uint32_t pitch);
 template <int PROJ>
@@ -69,6 +70,7 @@ struct mrt_ctx {
     // frame buffers (grown on demand)
     float* d_t = nullptr;
     int32_t* d_id = nullptr;
+    unsigned long long* d_key = nullptr;     // trace_kernel's working plane: (t, id) keys under atomicMin
     size_t plane_elems = 0;
     uint32_t* d_out = nullptr;
     size_t out_elems = 0;
@@ -472,9 +474,11 @@ int ensure_planes(mrt_ctx* ctx, size_t elems) {
     if (elems <= ctx->plane_elems) return MRT_OK;
     if (ctx->d_t) { (void)hipFree(ctx->d_t); ctx->d_t = nullptr; }
     if (ctx->d_id) { (void)hipFree(ctx->d_id); ctx->d_id = nullptr; }
+    if (ctx->d_key) { (void)hipFree(ctx->d_key); ctx->d_key = nullptr; }
     ctx->plane_elems = 0;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_t, elems * sizeof(float)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_id, elems * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_key, elems * sizeof(unsigned long long)));
     ctx->plane_elems = elems;
     return MRT_OK;
 }
@@ -542,13 +546,13 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     else if (cull)
         hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_ORTHO>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
     else if (persp && block)
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true>), tgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
     else if (persp)
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false>), tgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
     else if (block)
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true>), tgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
     else
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false>), tgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
     HIP_TRY(ctx, hipGetLastError());
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     if (!p.fuse_shade) {
@@ -634,6 +638,7 @@ void mrt_destroy(mrt_ctx* ctx) {
     free_dev(ctx->d_sph_mat); free_dev(ctx->d_mats); free_dev(ctx->d_lights);
     if (ctx->d_t) (void)hipFree(ctx->d_t);
     if (ctx->d_id) (void)hipFree(ctx->d_id);
+    if (ctx->d_key) (void)hipFree(ctx->d_key);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     for (int k = 0; k < 3; ++k) if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);

@@ -149,18 +149,22 @@ __device__ __forceinline__ void shade_row4(const RenderParams& p, uint32_t x0, u
     }
 }
 
-// Exact test of one primitive against the pixels of this lane's 4x4 block
-// whose bit is set in mask (bit r = row r/4, column r%4).  The closest hit so
-// far lives in the (t, id) planes in global memory -- each pixel belongs to
-// exactly one lane, so the read-modify-write needs no atomics -- which keeps
-// it out of the registers of the hot loop.  The loop runs until no lane of the
-// wave has a pixel left; lanes walk their own bits.
+// The closest hit of a pixel as one 64-bit key, (t bits << 32) | object id.  Accepted hits have
+// 0 < t < FLT_MAX, so keys order like (t, id), and the smallest key over all hits of a pixel is
+// the hit the reference's loop ends with: the smallest t, and among equal t the lowest object id
+// (strict "<" in object order, kernel.cl:326,344).  That holds in whatever order the pairs are
+// evaluated, which lets the kernels below hand pixels to whichever lane is free.
+constexpr unsigned long long kNoHitKey = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;   // (FLT_MAX, -1)
+
+// The reference arithmetic for one primitive over a list of pixels of the wave's 32x32 tile
+// (entry = 32 * row + column), 64 pixels at a time whichever lane owns them.  tile_ux / tile_uy
+// are the uv components of the tile's columns and rows; keys points at the tile's first pixel
+// in a key array with `stride` keys per row (LDS or global memory).
 template <int PROJ, bool TRI>
-__device__ __forceinline__ void exact_pass(const RenderParams& p, uint32_t mask, uint32_t prim, uint32_t x0,
-                                           uint32_t lr0, float* __restrict__ t_plane,
-                                           int32_t* __restrict__ id_plane, uint32_t pitch,
-                                           unsigned long long& n_exact) {
-    const float t_lower = 0.0f;   // scene::intersect, gfxraytrace.hpp:812
+__device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim, uint32_t total, int lane,
+                                           const uint16_t* __restrict__ list, const float* __restrict__ tile_ux,
+                                           const float* __restrict__ tile_uy, unsigned long long* __restrict__ keys,
+                                           uint32_t stride, unsigned long long& n_exact) {
     F3 A, B, C;
     float radius = 0.0f;
     if (TRI) {
@@ -173,45 +177,64 @@ __device__ __forceinline__ void exact_pass(const RenderParams& p, uint32_t mask,
         A = mk3(sp.x, sp.y, sp.z); B = A; C = A;
         radius = sp.w;
     }
-    const int32_t obj_id = (int32_t)(TRI ? p.n_sph + prim : prim);   // spheres first, gfxraytrace.hpp:701-714
-    const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
-    while (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
-        if (mask != 0) {
-            const uint32_t r = (uint32_t)__builtin_ctz(mask);
-            mask &= mask - 1;
-            const uint32_t x = x0 + (r & 3u), lr = lr0 + (r >> 2);
-            const uint32_t y = image_row(p, lr < last_row ? lr : last_row);
-            // gfxraytrace.hpp:850-852: pixel grid is (x + 1, y + 1) as floats.
-            const float ux = uv_component(p.left, p.right, (float)x + 1.0f, p.xres_f);
-            const float uy = uv_component(p.bottom, p.top, (float)y + 1.0f, p.yres_f);
+    const uint32_t obj_id = TRI ? p.n_sph + prim : prim;          // spheres first, gfxraytrace.hpp:701-714
+    for (uint32_t b = 0; b < total; b += 64) {
+        const uint32_t idx = b + (uint32_t)lane;
+        if (idx < total) {
+            const uint32_t px = list[idx];
             F3 o, d;
-            pixel_ray<PROJ>(p, ux, uy, o, d);
-            const size_t off = (size_t)lr * pitch + x;
-            const float bound = t_plane[off];    // temp_max, kernel.cl:307,336
+            pixel_ray<PROJ>(p, tile_ux[px & 31u], tile_uy[px >> 5], o, d);
             float t;
             bool hit, two;
-            // tri_intersect / circle_intersect against the current bound
-            // (kernel.cl:324,341), then the loop's strict acceptance (:326,:344).
-            if (TRI) hit = tri_exact(A, B, C, o, d, bound, t_lower, t);
-            else hit = sphere_exact(A, radius, o, d, bound, t_lower, t, two);
-            if (hit && t > t_lower && t < bound) {
-                t_plane[off] = t;
-                id_plane[off] = obj_id;
-            }
+            // Bounds of scene::intersect (gfxraytrace.hpp:812-813); the running bound of the
+            // reference's loop only rejects what the minimum rejects too.
+            if (TRI) hit = tri_exact(A, B, C, o, d, FLT_MAX, 0.0f, t);
+            else hit = sphere_exact(A, radius, o, d, FLT_MAX, 0.0f, t, two);
+            if (hit && t > 0.0f && t < FLT_MAX)
+                atomicMin(&keys[(size_t)(px >> 5) * stride + (px & 31u)],
+                          ((unsigned long long)__float_as_uint(t) << 32) | obj_id);
             ++n_exact;
         }
     }
+}
+
+// Lists the pixels of `mask` (bit r = row r/4, column r%4 of the lane's 4x4 block at (bx, by)
+// inside the tile) in `list`; returns how many pixels the whole wave listed.  LDS operations of
+// one wave complete in order and the arrays belong to this wave alone, so wave-level fences are
+// all the synchronisation needed.
+__device__ __forceinline__ uint32_t list_pixels(uint32_t mask, uint32_t bx, uint32_t by, int lane,
+                                                uint16_t* __restrict__ list, uint32_t* __restrict__ count) {
+    const uint32_t c = (uint32_t)__builtin_popcount(mask);
+    uint32_t at = 0;
+    if (c) at = atomicAdd(count, c);
+    while (mask) {
+        const uint32_t r = (uint32_t)__builtin_ctz(mask);
+        mask &= mask - 1;
+        list[at++] = (uint16_t)((by + (r >> 2)) * kWaveTile + bx + (r & 3u));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t total = *count;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) *count = 0;
+    return (uint32_t)__builtin_amdgcn_readfirstlane(total);
 }
 
 }  // namespace
 
 template <int PROJ, bool BLOCK_REJECT>
 __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace_kernel(const RenderParams p,
+                                                             unsigned long long* __restrict__ key_plane,
                                                              float* __restrict__ t_out,
                                                              int32_t* __restrict__ id_out,
                                                              uint32_t pitch) {
     __shared__ float4 s_rec[kChunkFloat4];
     __shared__ float4 s_circ[kChunkTris];
+    // per wave: the pixels one primitive still has to be tested on, and the tile's uv components
+    __shared__ uint16_t s_list[kBlockThreads / 64][kWaveTile * kWaveTile];
+    __shared__ float s_ux[kBlockThreads / 64][kWaveTile], s_uy[kBlockThreads / 64][kWaveTile];
+    __shared__ uint32_t s_count[kBlockThreads / 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -233,17 +256,34 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
         yf[j] = (float)image_row(p, lr < last_row ? lr : last_row);
     }
 
-    // Closest hit so far: t = FLT_MAX (scene::intersect's upper bound,
-    // gfxraytrace.hpp:813), id = -1.  The planes are padded to whole block
-    // tiles, so no bounds checks: four aligned 16-byte row segments per plane.
+    // Closest hit so far, one key per pixel in global memory: (FLT_MAX, -1), scene::intersect's
+    // upper bound (gfxraytrace.hpp:813) and "no object".  The planes are padded to whole block
+    // tiles, so no bounds checks.  Also the uv components of the tile's 32 columns and 32 rows
+    // (gfxraytrace.hpp:850-852: the pixel grid is (x + 1, y + 1)) for the exact step.
+    const uint32_t bx = (lane & 7) * kLanePx, by = (lane >> 3) * kLanePx;
+    uint16_t* list = s_list[wave];
+    float* tile_ux = s_ux[wave];
+    float* tile_uy = s_uy[wave];
+    uint32_t* list_count = &s_count[wave];
+    unsigned long long* tile_keys = key_plane + (size_t)wave_lr0 * pitch + wave_x0;
     if (wave_active) {
 #pragma unroll
         for (int j = 0; j < kLanePx; ++j) {
-            const size_t off = (size_t)(lr0 + j) * pitch + x0;
-            *reinterpret_cast<float4*>(t_out + off) = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX);
-            *reinterpret_cast<int4*>(id_out + off) = make_int4(-1, -1, -1, -1);
+            ulonglong2* row = reinterpret_cast<ulonglong2*>(key_plane + (size_t)(lr0 + j) * pitch + x0);
+            row[0] = make_ulonglong2(kNoHitKey, kNoHitKey);
+            row[1] = make_ulonglong2(kNoHitKey, kNoHitKey);
         }
+        const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
+        const uint32_t k = lane & 31;
+        if (lane < 32) {
+            tile_ux[k] = uv_component(p.left, p.right, (float)(wave_x0 + k) + 1.0f, p.xres_f);
+        } else {
+            const uint32_t lr = wave_lr0 + k;
+            tile_uy[k] = uv_component(p.bottom, p.top, (float)image_row(p, lr < last_row ? lr : last_row) + 1.0f, p.yres_f);
+        }
+        if (lane == 0) *list_count = 0;
     }
+    // (the first __syncthreads() of the chunk loops below orders these writes before their use)
 
     unsigned long long n_exact = 0;
     const bool no_prefilter = (p.flags & MRT_FLAG_NO_PREFILTER) != 0;
@@ -297,7 +337,9 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                     du += e.x;
                 }
                 if (no_prefilter) mask = 0xFFFFu;
-                exact_pass<PROJ, false>(p, mask, si, x0, lr0, t_out, id_out, pitch, n_exact);
+                if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
+                const uint32_t total = list_pixels(mask, bx, by, lane, list, list_count);
+                exact_list<PROJ, false>(p, si, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact);
             }
         }
     }
@@ -425,24 +467,33 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                     }
                 }
                 if (no_prefilter) mask = 0xFFFFu;
-                exact_pass<PROJ, true>(p, mask, ti, x0, lr0, t_out, id_out, pitch, n_exact);
+                if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
+                const uint32_t total = list_pixels(mask, bx, by, lane, list, list_count);
+                exact_list<PROJ, true>(p, ti, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact);
             }
         }
         }
     }
 
     if (wave_active) {
-        // intersect.t_ of a miss is -1 (kernel.cl:363).
+        // The atomics went to the device's L2; make sure the loads below see them.
+        __threadfence();
 #pragma unroll
         for (int j = 0; j < kLanePx; ++j) {
             const size_t off = (size_t)(lr0 + j) * pitch + x0;
-            float4 tv = *reinterpret_cast<const float4*>(t_out + off);
-            const int4 iv = *reinterpret_cast<const int4*>(id_out + off);
-            tv.x = iv.x < 0 ? -1.0f : tv.x;
-            tv.y = iv.y < 0 ? -1.0f : tv.y;
-            tv.z = iv.z < 0 ? -1.0f : tv.z;
-            tv.w = iv.w < 0 ? -1.0f : tv.w;
+            const ulonglong2* row = reinterpret_cast<const ulonglong2*>(key_plane + off);
+            const ulonglong2 k01 = row[0], k23 = row[1];
+            int4 iv;
+            float4 tv;
+            iv.x = (int32_t)(uint32_t)k01.x; iv.y = (int32_t)(uint32_t)k01.y;
+            iv.z = (int32_t)(uint32_t)k23.x; iv.w = (int32_t)(uint32_t)k23.y;
+            // intersect.t_ of a miss is -1 (kernel.cl:363).
+            tv.x = iv.x < 0 ? -1.0f : __uint_as_float((uint32_t)(k01.x >> 32));
+            tv.y = iv.y < 0 ? -1.0f : __uint_as_float((uint32_t)(k01.y >> 32));
+            tv.z = iv.z < 0 ? -1.0f : __uint_as_float((uint32_t)(k23.x >> 32));
+            tv.w = iv.w < 0 ? -1.0f : __uint_as_float((uint32_t)(k23.y >> 32));
             *reinterpret_cast<float4*>(t_out + off) = tv;
+            *reinterpret_cast<int4*>(id_out + off) = iv;
             // Shade this row segment here rather than in a second launch: four pixels, one
             // aligned 16-byte RGBA8 store per lane, 128 contiguous bytes per lane row of the wave.
             if (p.fuse_shade) shade_row4<PROJ>(p, x0, lr0 + j, tv, iv);
@@ -471,50 +522,6 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
 // pairs are evaluated.  Needs a tile's 32 rows to be consecutive image rows
 // (band height a multiple of 32); the host falls back to trace_kernel otherwise.
 // ---------------------------------------------------------------------------
-constexpr unsigned long long kNoHitKey = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;   // (FLT_MAX, -1)
-
-namespace {
-
-// The reference arithmetic for one primitive over the listed pixels of the tile.
-template <int PROJ, bool TRI>
-__device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim, uint32_t total, int lane,
-                                           const uint16_t* __restrict__ list, const float* __restrict__ tile_ux,
-                                           const float* __restrict__ tile_uy, unsigned long long* __restrict__ keys,
-                                           unsigned long long& n_exact) {
-    F3 A, B, C;
-    float radius = 0.0f;
-    if (TRI) {
-        const float4 va = p.tri_exact[(size_t)prim * 3 + 0];
-        const float4 vb = p.tri_exact[(size_t)prim * 3 + 1];
-        const float4 vc = p.tri_exact[(size_t)prim * 3 + 2];
-        A = mk3(va.x, va.y, va.z); B = mk3(vb.x, vb.y, vb.z); C = mk3(vc.x, vc.y, vc.z);
-    } else {
-        const float4 sp = p.sph[prim];
-        A = mk3(sp.x, sp.y, sp.z); B = A; C = A;
-        radius = sp.w;
-    }
-    const uint32_t obj_id = TRI ? p.n_sph + prim : prim;          // spheres first, gfxraytrace.hpp:701-714
-    for (uint32_t b = 0; b < total; b += 64) {
-        const uint32_t idx = b + (uint32_t)lane;
-        if (idx < total) {
-            const uint32_t px = list[idx];
-            F3 o, d;
-            pixel_ray<PROJ>(p, tile_ux[px & 31u], tile_uy[px >> 5], o, d);
-            float t;
-            bool hit, two;
-            // Bounds of scene::intersect (gfxraytrace.hpp:812-813); the running bound of the
-            // reference's loop only rejects what the minimum below rejects too.
-            if (TRI) hit = tri_exact(A, B, C, o, d, FLT_MAX, 0.0f, t);
-            else hit = sphere_exact(A, radius, o, d, FLT_MAX, 0.0f, t, two);
-            if (hit && t > 0.0f && t < FLT_MAX)
-                atomicMin(&keys[px], ((unsigned long long)__float_as_uint(t) << 32) | obj_id);
-            ++n_exact;
-        }
-    }
-}
-
-}  // namespace
-
 template <int PROJ>
 __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderParams p,
                                                                   float* __restrict__ t_out,
@@ -569,26 +576,6 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     unsigned long long n_exact = 0;
 
-    // Writes the pixels of `mask` (bit r = row r/4, column r%4 of this lane's block) to the
-    // list; returns how many pixels the whole wave listed.
-    auto list_pixels = [&](uint32_t mask) -> uint32_t {
-        const uint32_t c = (uint32_t)__builtin_popcount(mask);
-        uint32_t at = 0;
-        if (c) at = atomicAdd(&s_count[wave], c);
-        while (mask) {
-            const uint32_t r = (uint32_t)__builtin_ctz(mask);
-            mask &= mask - 1;
-            list[at++] = (uint16_t)((by + (r >> 2)) * kWaveTile + bx + (r & 3u));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t total = s_count[wave];
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) s_count[wave] = 0;
-        return (uint32_t)__builtin_amdgcn_readfirstlane(total);
-    };
-
     // ---- spheres ----
     for (uint32_t base = 0; base < p.n_sph; base += 64) {
         const float4 e = p.sph_filter[base + lane];          // padded to a multiple of 768
@@ -616,8 +603,8 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
                 dup += fx;
             }
             if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
-            const uint32_t total = list_pixels(mask);
-            exact_list<PROJ, false>(p, si, total, lane, list, tile_ux, tile_uy, keys, n_exact);
+            const uint32_t total = list_pixels(mask, bx, by, lane, list, &s_count[wave]);
+            exact_list<PROJ, false>(p, si, total, lane, list, tile_ux, tile_uy, keys, kWaveTile, n_exact);
         }
     }
 
@@ -675,8 +662,8 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
                 }
             }
             if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
-            const uint32_t total = list_pixels(mask);
-            exact_list<PROJ, true>(p, ti, total, lane, list, tile_ux, tile_uy, keys, n_exact);
+            const uint32_t total = list_pixels(mask, bx, by, lane, list, &s_count[wave]);
+            exact_list<PROJ, true>(p, ti, total, lane, list, tile_ux, tile_uy, keys, kWaveTile, n_exact);
         }
     }
 
@@ -1034,10 +1021,10 @@ __global__ __launch_bounds__(256) void shade_kernel(const RenderParams p,
     p.out[(size_t)lr * p.xres + x] = shade_pixel<PROJ>(p, x, image_row(p, lr), t_in[src], id_in[src]);
 }
 
-template __global__ void trace_kernel<MRT_PROJ_ORTHO, false>(const RenderParams, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_PERSP, false>(const RenderParams, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_ORTHO, true>(const RenderParams, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_PERSP, true>(const RenderParams, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, false>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, false>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, true>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, true>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void full_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, float*, int32_t*, uint32_t);
 template __global__ void full_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, float*, int32_t*, uint32_t);
 template __global__ void prep_full_records<MRT_PROJ_ORTHO>(const RenderParams, float4*, uint32_t*, uint32_t*);
