@@ -36,8 +36,8 @@ constexpr int kGroupSph = 4;
 constexpr int kGroupCircle = MRT_GROUP_CIRCLE;   // triangles per vote of the bounding-circle test (a multiple of kGroupTris)
 
 // Register budget of trace_kernel in waves per SIMD.  6 (<= 80 VGPRs) is what
-// the kernel needs without spilling; 8 (64 VGPRs, small spills in the exact
-// pass) measured the same on teatime 4K because the loop is VALU-issue bound.
+// the kernel needs without spilling in its hot loop; 7 measured the same and 8
+// (64 VGPRs, spills) 7 % slower on teatime 4K.
 #ifndef MRT_TRACE_WAVES_PER_SIMD
 #define MRT_TRACE_WAVES_PER_SIMD 6
 #endif
