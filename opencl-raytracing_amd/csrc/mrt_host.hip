@@ -30,6 +30,9 @@ template <int PROJ>
 __global__ void prep_full_records(const RenderParams p, float4* rec, uint32_t* ids, uint32_t* counts);
 template <int PROJ>
 __global__ void shade_kernel(const RenderParams p, const float* t_in, const int32_t* id_in, uint32_t pitch);
+template <int PROJ>
+__global__ void shade_keys_kernel(const RenderParams p, const unsigned long long* key_plane, float* t_out,
+                                  int32_t* id_out, uint32_t pitch);
 }  // namespace mrt
 
 using mrt::RenderParams;
@@ -535,6 +538,28 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     // low occupancy and leaves shading to shade_kernel.
     const bool full = (ctx->flags & MRT_FLAG_FULL_TEST) != 0;
     p.fuse_shade = (cull && !full) ? 0u : ((p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u);
+    // A frame with few tiles cannot fill the GPU with one wave per tile walking the whole triangle
+    // list (a wave alone on its SIMD issues at a fraction of the rate six of them reach together),
+    // so trace_kernel then gets the list in slices, one grid layer each; the (t, id) keys merge them.
+    p.prim_slices = 1;
+    p.slice_tris = p.n_tri_padded;
+    const bool sliced_path = !full && !cull;
+    if (sliced_path) {
+        const uint32_t waves = tgrid.x * tgrid.y * (mrt::kBlockThreads / 64);
+        const uint32_t chunks = p.n_tri_padded / mrt::kChunkTris;
+        if (waves < 4096 && chunks > 1) {
+            uint32_t want = (8192 + waves - 1) / waves;
+            if (want > chunks) want = chunks;
+            const uint32_t per = (chunks + want - 1) / want;
+            p.slice_tris = per * mrt::kChunkTris;
+            p.prim_slices = (chunks + per - 1) / per;
+        }
+    }
+    const dim3 zgrid(tgrid.x, tgrid.y, p.prim_slices);
+    if (p.prim_slices > 1) {
+        p.fuse_shade = (p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_key, 0xFF, (size_t)pitch * prow * sizeof(unsigned long long), stream));
+    }
     if ((ctx->flags & MRT_FLAG_FULL_TEST) && persp)
         hipLaunchKernelGGL((mrt::full_trace_kernel<MRT_PROJ_PERSP>), fgrid, tb, 0, stream, p,
                            (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, ctx->d_t, ctx->d_id, pitch);
@@ -546,16 +571,23 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     else if (cull)
         hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_ORTHO>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
     else if (persp && block)
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true>), tgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true>), zgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
     else if (persp)
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false>), tgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false>), zgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
     else if (block)
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true>), tgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true>), zgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
     else
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false>), tgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false>), zgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
     HIP_TRY(ctx, hipGetLastError());
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
-    if (!p.fuse_shade) {
+    if (p.prim_slices > 1) {
+        const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
+        if (persp)
+            hipLaunchKernelGGL(mrt::shade_keys_kernel<MRT_PROJ_PERSP>, sgrid, dim3(256), 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
+        else
+            hipLaunchKernelGGL(mrt::shade_keys_kernel<MRT_PROJ_ORTHO>, sgrid, dim3(256), 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
+        HIP_TRY(ctx, hipGetLastError());
+    } else if (!p.fuse_shade) {
         const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
         if (persp)
             hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_PERSP>, sgrid, dim3(256), 0, stream, p, ctx->d_t, ctx->d_id, pitch);

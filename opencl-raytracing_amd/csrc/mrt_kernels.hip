@@ -266,12 +266,19 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     float* tile_uy = s_uy[wave];
     uint32_t* list_count = &s_count[wave];
     unsigned long long* tile_keys = key_plane + (size_t)wave_lr0 * pitch + wave_x0;
+    // Small frames do not have enough tiles to fill the GPU, so the host may cut the triangle list
+    // into blockIdx.z slices of p.slice_tris triangles (the keys merge them: their minimum does
+    // not depend on who found a hit).  It then initialises the key plane itself, before the
+    // launch, and shades in shade_keys_kernel, after it; a single slice does both here.
+    const bool single_slice = p.prim_slices <= 1;
     if (wave_active) {
+        if (single_slice) {
 #pragma unroll
-        for (int j = 0; j < kLanePx; ++j) {
-            ulonglong2* row = reinterpret_cast<ulonglong2*>(key_plane + (size_t)(lr0 + j) * pitch + x0);
-            row[0] = make_ulonglong2(kNoHitKey, kNoHitKey);
-            row[1] = make_ulonglong2(kNoHitKey, kNoHitKey);
+            for (int j = 0; j < kLanePx; ++j) {
+                ulonglong2* row = reinterpret_cast<ulonglong2*>(key_plane + (size_t)(lr0 + j) * pitch + x0);
+                row[0] = make_ulonglong2(kNoHitKey, kNoHitKey);
+                row[1] = make_ulonglong2(kNoHitKey, kNoHitKey);
+            }
         }
         const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
         const uint32_t k = lane & 31;
@@ -293,7 +300,8 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     // Record (sx, ox, sy, oy): the pixel can only hit if
     // (x*sx + ox)^2 + (y*sy + oy)^2 <= 1, an ellipse around the sphere's
     // projected bounding box grown by the error margin.
-    for (uint32_t base = 0; base < p.n_sph_padded; base += kChunkFloat4) {
+    const uint32_t sph_end = blockIdx.z == 0 ? p.n_sph_padded : 0u;       // spheres go with the first slice
+    for (uint32_t base = 0; base < sph_end; base += kChunkFloat4) {
         __syncthreads();
         stage_chunk(s_rec, p.sph_filter + base, tid);
         __syncthreads();
@@ -347,7 +355,10 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     // ---- triangles: object ids n_sph .. n_sph+n_tri-1 ----
     // Record: 12 floats (A0,B0,C0,A1 | B1,C1,A2,B2 | C2,-,-,-); edge k passes at
     // pixel (x, y) when A_k*x + B_k*y + C_k >= 0.
-    for (uint32_t base = 0; base < p.n_tri_padded; base += kChunkTris) {
+    const uint32_t tri_begin = single_slice ? 0u : blockIdx.z * p.slice_tris;
+    const uint32_t tri_end = single_slice ? p.n_tri_padded
+                                          : (tri_begin + p.slice_tris < p.n_tri_padded ? tri_begin + p.slice_tris : p.n_tri_padded);
+    for (uint32_t base = tri_begin; base < tri_end; base += kChunkTris) {
         __syncthreads();
         stage_chunk(s_rec, p.tri_filter + (size_t)base * 3, tid);
 #pragma unroll
@@ -475,7 +486,9 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
         }
     }
 
-    if (wave_active) {
+    if (wave_active && !single_slice) {
+        if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
+    } else if (wave_active) {
         // The atomics went to the device's L2; make sure the loads below see them.
         __threadfence();
 #pragma unroll
@@ -1006,6 +1019,26 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
     }
 }
 
+// The epilogue of trace_kernel as a launch of its own, for frames traced in several slices: one
+// thread per pixel decodes the key, writes the (t, id) planes and shades.  A key the host's
+// byte-wise initialisation left untouched is all ones: id -1, a miss.
+template <int PROJ>
+__global__ __launch_bounds__(256) void shade_keys_kernel(const RenderParams p,
+                                                        const unsigned long long* __restrict__ key_plane,
+                                                        float* __restrict__ t_out, int32_t* __restrict__ id_out,
+                                                        uint32_t pitch) {
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t lr = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.xres || lr >= p.local_rows) return;
+    const size_t src = (size_t)lr * pitch + x;
+    const unsigned long long key = key_plane[src];
+    const int32_t id = (int32_t)(uint32_t)key;
+    const float t = id < 0 ? -1.0f : __uint_as_float((uint32_t)(key >> 32));     // kernel.cl:363
+    t_out[src] = t;
+    id_out[src] = id;
+    p.out[(size_t)lr * p.xres + x] = shade_pixel<PROJ>(p, x, image_row(p, lr), t, id);
+}
+
 // Shading as a launch of its own, one thread per pixel (a wave writes 256 contiguous bytes of
 // RGBA8), for cull_trace_kernel: at its three waves per SIMD the long dependent chains of
 // phong_light (normalise, pow, divide) are better hidden by a kernel that needs few registers.
@@ -1032,6 +1065,8 @@ template __global__ void prep_full_records<MRT_PROJ_PERSP>(const RenderParams, f
 template __global__ void cull_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void cull_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, float*, int32_t*, uint32_t);
 
+template __global__ void shade_keys_kernel<MRT_PROJ_ORTHO>(const RenderParams, const unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void shade_keys_kernel<MRT_PROJ_PERSP>(const RenderParams, const unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void shade_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float*, const int32_t*, uint32_t);
 template __global__ void shade_kernel<MRT_PROJ_PERSP>(const RenderParams, const float*, const int32_t*, uint32_t);
 

@@ -58,6 +58,7 @@ struct RenderParams {
     uint32_t band_rows, rank, world;  // interleaved row-band partition
     uint32_t local_rows;            // rows this launch renders (packed)
     uint32_t n_sph, n_tri, n_tri_padded, n_sph_padded, n_lights;
+    uint32_t prim_slices, slice_tris;   // trace_kernel: triangle list cut into blockIdx.z slices (1 = whole list)
     const float4* sph_filter;       // 1 x float4 per sphere, padded to kChunkFloat4
     const float4* tri_filter;       // 3 x float4 per triangle, padded to kChunkTris
     const float4* tri_circle;       // (xc, yc, R^2, -) per triangle, padded to kChunkTris
