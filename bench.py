@@ -227,6 +227,11 @@ def secondary_workloads(env, mkscene):
     frame_stats(job, "teatime_8k_7680x4320", steps=5, warmup=1, extra={"scaling": "strong"})
     job.close()
     if env.world == 1:
+        # The shipped scenes at their native 400 x 400 (the only size the reference itself can render).
+        for name in ("scene_2spheres_persp_phong", "scene_gtri_persp_phong", "teatime"):
+            job = Job(env, mrt.LoadedScene(path=ROOT / "scenes" / f"{name}.json").copy())
+            frame_stats(job, f"native_400x400_{name}", steps=20, warmup=2)
+            job.close()
         # The headline frame with parts of the rejection funnel switched off / the opt-in block form.
         sc4k = mrt.LoadedScene(text=mkscene.teatime(XRES, YRES)).copy()
         for label, flags, steps in (("teatime_4k_edge_test_only_no_circle", mrt.FLAG_NO_CIRCLE, 5),
