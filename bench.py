@@ -14,16 +14,20 @@ scaling: fixed work per GPU), and every step gathers all bands to rank 0 over
 RCCL; the gather of frame k runs on RCCL's stream while frame k+1 renders (two
 buffer sets).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel
-(trace_kernel): algorithmic FLOPs per launch = rays * (4032 * 45 + 2 * 20)
-(45 FLOPs per ray-triangle test, 20 per ray-sphere test, brute force, no
-culling credit) over the kernel's mean duration measured with HIP events on
-the launch stream, against the 157.3 TFLOP/s FP32 vector peak.  `cpu_baseline`
-times the CPU oracle (oracle/mrt_oracle.c, a restatement of the reference
-arithmetic -- the reference has no CPU path of its own and may not be run) on
-a bounded row sample of the same frame.  `secondary` carries the other
-benchmark configurations (8K frame, the 16384^2 triangle soup split over the N
-ranks, and the headline frame with parts of the rejection funnel switched off).
+Rank 0 prints ONE JSON line.  `value` is the throughput of the library's default path
+(trace_kernel: every ray x every primitive, most pairs settled by a conservative per-pixel
+predicate, the reference arithmetic for the survivors).  `roofline` is NOT about that kernel --
+its executed arithmetic is a small fraction of the priced arithmetic -- but about
+full_trace_kernel (MRT_FLAG_FULL_TEST), the kernel that evaluates a general-ray 3x3 solve for
+every (ray, triangle) pair, timed in the same run on the same frame with HIP events on its launch
+stream: algorithmic FLOPs per launch = rays * (4032 * 45 + 2 * 20) (45 per ray-triangle test, 20
+per ray-sphere test, no culling credit) over its mean duration, against the 157.3 TFLOP/s FP32
+vector peak.  The default path is described beside it by flat keys (default_*), among them the
+executed VALU issue rate as a fraction of the nominal 78.6 T lane-ops/s.  `cpu_baseline` times
+the CPU oracle (oracle/mrt_oracle.c, a restatement of the reference arithmetic -- the reference
+has no CPU path of its own and may not be run) on a bounded row sample of the same frame.
+`secondary` carries the other benchmark configurations; with N > 1 the strong-scaling frames
+(16384^2 soup, 8K teatime) are also reported as flat soup16k_* / teatime8k_* keys.
 """
 import argparse
 import json
@@ -40,6 +44,7 @@ sys.path.insert(0, str(ROOT / "tools"))
 FLOPS_PER_TRI_TEST = 45.0
 FLOPS_PER_SPH_TEST = 20.0
 FP32_PEAK_TFLOPS = 157.3          # 256 CU x 128 lanes x 2 FLOP x 2.4 GHz
+VALU_ISSUE_PEAK = 78.6e12         # lane-ops/s: 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
 BAND_ROWS = 64
 XRES, YRES = 3840, 2160
 
@@ -74,46 +79,28 @@ def cpu_baseline(sc, seconds_target=12.0):
     }
 
 
-def profiled_traffic():
-    """HBM bytes per trace_kernel launch from the committed rocprofv3 counter passes of this same
-    command (FETCH_SIZE and WRITE_SIZE are collected in separate --pmc runs, in KiB; on gfx950
-    FETCH_SIZE counts 16-byte-per-lane reads at half their size, hence the factor 2)."""
-    best = None
-    for f in sorted((ROOT / "profiles").glob("r*/teatime4k_pmc_summary.json")):
-        best = f
-    if best is None:
-        return None, None
-    try:
-        data = json.loads(best.read_text())
-        for name, entry in data.items():
-            if "mrt::trace_kernel" in name:
-                c = entry["counters_mean_per_launch"]
-                return c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024, str(best.relative_to(ROOT))
-    except (KeyError, ValueError):
-        pass
-    return None, None
-
-
-def profiled_valu_issue(kernel="mrt::trace_kernel", ideal=2.33):
-    """VALU issue utilisation of one kernel from the same committed counter passes: wave
-    instructions per SIMD (256 CUs x 4) over the launch's GPU cycles (GRBM_GUI_ACTIVE is summed
-    over the 8 XCDs), against the cycles its instruction mix needs at the issue rates measured
-    with tools/valu_bench.hip (2 cycles for full-rate ops, 3.3 for three-source ops, 4 for
-    two-source min/max: 2.33 on average for trace_kernel, 2.09 for full_trace_kernel)."""
+def profiled_counters(kernel):
+    """Mean hardware counters per launch of one kernel from the newest committed rocprofv3 passes
+    of this same command (profiles/rNN/teatime4k_pmc_summary.json, made by tools/profile.sh and
+    tools/summarize_profile.py), or (None, None)."""
     for f in sorted((ROOT / "profiles").glob("r*/teatime4k_pmc_summary.json"), reverse=True):
         try:
             for name, entry in json.loads(f.read_text()).items():
                 if kernel in name:
-                    c = entry["counters_mean_per_launch"]
-                    cycles = c["GRBM_GUI_ACTIVE"] / 8.0
-                    per_inst = cycles / (c["SQ_INSTS_VALU"] / 1024.0)
-                    return {"insts_valu_per_launch": c["SQ_INSTS_VALU"], "gpu_cycles_per_launch": cycles,
-                            "cycles_per_inst_per_simd": per_inst, "ideal_cycles_per_inst": ideal,
-                            "util": ideal / per_inst, "lds_bank_conflicts": c.get("SQ_LDS_BANK_CONFLICT"),
-                            "source": str(f.relative_to(ROOT))}
-        except (KeyError, ValueError, ZeroDivisionError):
+                    return entry["counters_mean_per_launch"], str(f.relative_to(ROOT))
+        except (KeyError, ValueError):
             continue
-    return None
+    return None, None
+
+
+def profiled_traffic(c):
+    """Bytes per launch that crossed the L2 -> fabric boundary (FETCH_SIZE and WRITE_SIZE are
+    collected in separate --pmc runs, in KiB; on gfx950 FETCH_SIZE counts 16-byte-per-lane reads
+    at half their size, hence the factor 2)."""
+    try:
+        return c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
+    except (KeyError, TypeError):
+        return None
 
 
 class Env:
@@ -327,17 +314,32 @@ def main():
     job = Job(env, sc)
     elapsed = job.timed(args.steps, args.warmup)
     trace_avg, shade_avg = job.kernel_ms(max(10, min(args.steps, 50)))
+    host = host_frame(env, job, st.xres * st.yres) if (world == 1 and rank == 0) else None
+    job.close()
+
+    # The same frame (this rank's rows of it) with MRT_FLAG_FULL_TEST: no rejection in screen space,
+    # a general-ray 3x3 solve for every (ray, triangle) pair -- the kernel whose executed arithmetic
+    # is the priced arithmetic, hence the one the roofline is about.
+    fjob = Job(env, sc, flags=mrt.FLAG_FULL_TEST)
+    full_reps = max(3, min(args.steps, 10))
+    full_elapsed = fjob.timed(full_reps, 1)
+    full_trace, _ = fjob.kernel_ms(full_reps)
+    full_rows = fjob.rows
+    fjob.close()
 
     out = None
     if rank == 0:
         total_rays = st.xres * st.yres                      # all ranks together, per step
         n_prims = st.n_spheres + st.n_tris
         value = total_rays * args.steps / elapsed * 1e-6
-        flops_launch = algorithmic_flops(st, job.rows * st.xres)
-        achieved = flops_launch / (trace_avg * 1e-3) * 1e-12
-        traffic, traffic_src = profiled_traffic() if world == 1 else (None, None)
+        flops_launch = algorithmic_flops(st, full_rows * st.xres)
+        pairs_launch = full_rows * st.xres * n_prims
+        achieved = flops_launch / (full_trace * 1e-3) * 1e-12
+        fc, fsrc = profiled_counters("mrt::full_trace_kernel") if world == 1 else (None, None)
+        dc, dsrc = profiled_counters("mrt::trace_kernel") if world == 1 else (None, None)
         out = {
-            "metric": "Mrays/s, teatime 3840x2160 Blinn-Phong, brute-force closest hit over 4034 primitives",
+            "metric": "Mrays/s, teatime 3840x2160 Blinn-Phong, exact closest hit of every ray over all 4034 "
+                      "primitives (default path: conservative per-pixel prefilter, reference arithmetic on survivors)",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -350,42 +352,49 @@ def main():
                        "output": "RGBA8 resident in HBM (no D2H in the timed region)"},
             "prim_tests_per_s": value * 1e6 * n_prims,
             "roofline": {
-                "bound": "valu", "kernel": "trace_kernel", "achieved": achieved, "peak": FP32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "kernel_ms": trace_avg, "shade_kernel_ms": shade_avg, "flops_per_launch": flops_launch,
-                "valu_issue": profiled_valu_issue() if world == 1 else None,
-                "note": "algorithmic FLOPs: 45 per ray-triangle test, 20 per ray-sphere test, every ray x "
-                        "every primitive; the kernel rejects most pairs per pixel with a one-FMA bounding-circle "
-                        "test, so executed FLOPs are far lower and frac exceeds 1; VALU issue utilisation from "
-                        "the committed SQ_INSTS_VALU counters is the kernel-quality figure",
+                "bound": "valu", "kernel": "full_trace_kernel", "kernel_ms": full_trace,
+                "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP32_PEAK_TFLOPS, "traffic": profiled_traffic(fc),
+                "flops_per_launch": flops_launch, "pairs_per_launch": pairs_launch,
+                "insts_valu_per_pair": (fc["SQ_INSTS_VALU"] * 64.0 / pairs_launch) if fc and "SQ_INSTS_VALU" in fc else None,
+                "exec_issue_frac": (fc["SQ_INSTS_VALU"] * 64.0 / (full_trace * 1e-3) / VALU_ISSUE_PEAK)
+                if fc and "SQ_INSTS_VALU" in fc else None,
+                "counters_source": fsrc,
+                "note": "MRT_FLAG_FULL_TEST kernel on the same frame in the same run: a general-ray 3x3 solve "
+                        "(determinants of tri_intersect) for every (ray, triangle) pair, no screen-space rejection; "
+                        "45 FLOP per ray-triangle test, 20 per ray-sphere test; same pixels as the default path",
             },
+            "full_test_ms_per_frame": full_elapsed / full_reps * 1e3,
+            "full_test_mrays_per_s": total_rays * full_reps / full_elapsed * 1e-6,
+            "full_test_prim_tests_per_s": total_rays * n_prims * full_reps / full_elapsed,
+            # the default path, whose throughput is `value`
+            "default_kernel": "trace_kernel (+ shade_keys_kernel)",
+            "default_kernel_ms": trace_avg, "default_shade_kernel_ms": shade_avg,
+            "default_insts_valu_per_pair": (dc["SQ_INSTS_VALU"] * 64.0 / pairs_launch) if dc and "SQ_INSTS_VALU" in dc else None,
+            "default_exec_issue_frac": (dc["SQ_INSTS_VALU"] * 64.0 / (trace_avg * 1e-3) / VALU_ISSUE_PEAK)
+            if dc and "SQ_INSTS_VALU" in dc else None,
+            "default_traffic": profiled_traffic(dc), "default_counters_source": dsrc,
+            "default_note": "the default kernel settles most pairs with a one-FMA bounding-circle test, so it is "
+                            "priced by executed VALU issue rate (SQ_INSTS_VALU x 64 lanes / kernel time / 78.6e12), "
+                            "not by algorithmic FLOPs",
         }
-        if world == 1:
-            out["host_frame"] = host_frame(env, job, total_rays)
-    job.close()
-    if world == 1:
-        # The same frame with MRT_FLAG_FULL_TEST: no rejection in screen space, every pair evaluates
-        # the reference's four determinants (33 unfused multiplies/adds) -- the row of the roofline
-        # whose executed arithmetic is the priced arithmetic.
-        fjob = Job(env, sc, flags=mrt.FLAG_FULL_TEST)
-        fjob.timed(1, 1)
-        f_trace, _ = fjob.kernel_ms(3)
-        fjob.close()
-        f_ach = flops_launch / (f_trace * 1e-3) * 1e-12
-        out["roofline"]["full_test_kernel"] = {
-            "kernel": "full_trace_kernel", "kernel_ms": f_trace, "mrays_per_s": total_rays / f_trace * 1e-3,
-            "achieved": f_ach, "frac": f_ach / FP32_PEAK_TFLOPS,
-            "valu_issue": profiled_valu_issue("mrt::full_trace_kernel", 2.09),
-            "note": "MRT_FLAG_FULL_TEST: determinants of tri_intersect for every (pixel, triangle) pair in the "
-                    "reference's operation order, divisions deferred; same pixels as the default path"}
+        if host is not None:
+            out["host_frame"] = host
     if not args.no_secondary:
         sec = secondary_workloads(env, mkscene)
         if rank == 0:
             out["secondary"] = sec
+            # strong scaling of one fixed frame over the N ranks, as flat keys
+            for key, name in (("soup16k", "soup16k_16384x16384"), ("teatime8k", "teatime_8k_7680x4320")):
+                if name in sec:
+                    out[f"{key}_ms_per_frame"] = sec[name]["ms_per_frame"]
+                    out[f"{key}_mrays_per_s"] = sec[name]["mrays_per_s"]
+                    out[f"{key}_scaling"] = "strong"
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sc)
+            out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            out["full_test_vs_cpu_baseline"] = out["full_test_mrays_per_s"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
 
     if env.use_dist:

@@ -19,9 +19,15 @@
  *   gfxraytrace.hpp:830 gfx::scene::render()       -> mrt_set_scene + mrt_render_rgba8
  *   CLStructs.hpp:8-128 packed AoS structs         -> mrt_scene (SoA planes) / mrt_cl_* (AoS mirrors)
  *
- * Threading: one mrt_ctx may be used from one thread at a time.  Distinct
- * contexts are independent.  All entry points return MRT_OK (0) or a negative
- * mrt_status; mrt_last_error() gives the text of the last failure on a ctx.
+ * Threading: one mrt_ctx may be used from one thread at a time, and frames of
+ * one ctx must be enqueued on one stream at a time (a ctx owns a single set of
+ * working buffers; the library orders a frame behind the previous frame of the
+ * same ctx when the stream changes, at the cost of a wait).  Distinct contexts
+ * are independent.
+ * Every entry point makes its ctx's GPU the current HIP device for its own
+ * duration and restores the caller's current device before it returns.  All
+ * entry points return MRT_OK (0) or a negative mrt_status; mrt_last_error()
+ * gives the text of the last failure on a ctx.
  */
 #ifndef MRT_H
 #define MRT_H
@@ -33,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 1
+#define MRT_ABI_VERSION 2
 
 typedef enum mrt_status {
     MRT_OK = 0,
@@ -131,7 +137,18 @@ typedef struct mrt_stats {
     uint64_t rays;          /* primary rays = pixels rendered                   */
     uint64_t prim_tests;    /* rays x (n_spheres + n_tris), brute force         */
     uint64_t exact_tests;   /* (pixel, primitive) pairs that reached the exact test (0 unless counted) */
+    uint32_t kernel;        /* MRT_KERNEL_*: the closest-hit kernel this frame ran                     */
+    uint32_t prim_slices;   /* grid layers the triangle list was cut into (trace kernel), else 1       */
 } mrt_stats;
+
+/* Which closest-hit kernel a frame ran (mrt_stats.kernel): the flags ask, the
+ * band geometry decides (see MRT_FLAG_BLOCK_REJECT / MRT_FLAG_SCREEN_CULL). */
+enum {
+    MRT_KERNEL_TRACE = 0,         /* per-pixel circle -> edge -> exact funnel (default)   */
+    MRT_KERNEL_TRACE_BLOCK = 1,   /* ... preceded by the 4x4 block reject                 */
+    MRT_KERNEL_CULL = 2,          /* 32x32 tile cull                                      */
+    MRT_KERNEL_FULL = 3           /* determinants for every pair (MRT_FLAG_FULL_TEST)     */
+};
 
 typedef struct mrt_ctx mrt_ctx;
 

@@ -22,6 +22,8 @@ FLAG_BLOCK_REJECT = 1 << 2
 FLAG_NO_CIRCLE = 1 << 3
 FLAG_SCREEN_CULL = 1 << 4
 FLAG_FULL_TEST = 1 << 5
+KERNEL_TRACE, KERNEL_TRACE_BLOCK, KERNEL_CULL, KERNEL_FULL = 0, 1, 2, 3    # mrt_stats.kernel
+ABI_VERSION = 2
 PROJ_ORTHO, PROJ_PERSP = 0, 1
 SHADER_FLAT, SHADER_PHONG = 0, 1
 
@@ -75,6 +77,7 @@ class Stats(C.Structure):
         ("upload_ms", C.c_double), ("kernel_ms", C.c_double), ("trace_ms", C.c_double),
         ("shade_ms", C.c_double), ("download_ms", C.c_double),
         ("rays", C.c_uint64), ("prim_tests", C.c_uint64), ("exact_tests", C.c_uint64),
+        ("kernel", C.c_uint32), ("prim_slices", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -75,10 +75,17 @@ struct mrt_ctx {
     float* d_t = nullptr;
     int32_t* d_id = nullptr;
     unsigned long long* d_key = nullptr;     // trace_kernel's working plane: (t, id) keys under atomicMin
-    size_t plane_elems = 0;
+    size_t plane_elems = 0, key_elems = 0;
     uint32_t* d_out = nullptr;
     size_t out_elems = 0;
     unsigned long long* d_counter = nullptr;
+
+    // The last frame enqueued: which kernel it ran, and an event behind it so that a frame on
+    // another stream can be ordered after it (the working planes above are shared by all frames).
+    uint32_t last_kernel = MRT_KERNEL_TRACE, last_slices = 1;
+    hipEvent_t frame_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool frame_pending = false;
 };
 
 namespace {
@@ -96,6 +103,27 @@ int fail(mrt_ctx* ctx, int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                               \
             return fail((ctx), MRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// Makes a ctx's GPU the current device for the duration of an entry point and puts the caller's
+// current device back afterwards (a process that drives several GPUs, or a framework with its own
+// notion of the current device, must not find it changed).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device);
+    }
+    ~DeviceGuard() {
+        int now = -1;
+        if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ENTER_DEVICE(ctx)                          \
+    DeviceGuard guard_((ctx)->device);              \
+    HIP_TRY((ctx), guard_.err)
 
 void free_dev(void*& p) {
     if (p) { (void)hipFree(p); p = nullptr; }
@@ -474,15 +502,24 @@ int check_scene(mrt_ctx* ctx, const mrt_scene* s) {
     return MRT_OK;
 }
 
+// Working planes of a frame, grown on demand: the 64-bit key plane of trace_kernel, and the
+// (t, id) planes that mrt_render_debug returns and cull_trace_kernel hands to shade_kernel.
+int ensure_keys(mrt_ctx* ctx, size_t elems) {
+    if (elems <= ctx->key_elems) return MRT_OK;
+    if (ctx->d_key) { (void)hipFree(ctx->d_key); ctx->d_key = nullptr; }
+    ctx->key_elems = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_key, elems * sizeof(unsigned long long)));
+    ctx->key_elems = elems;
+    return MRT_OK;
+}
+
 int ensure_planes(mrt_ctx* ctx, size_t elems) {
     if (elems <= ctx->plane_elems) return MRT_OK;
     if (ctx->d_t) { (void)hipFree(ctx->d_t); ctx->d_t = nullptr; }
     if (ctx->d_id) { (void)hipFree(ctx->d_id); ctx->d_id = nullptr; }
-    if (ctx->d_key) { (void)hipFree(ctx->d_key); ctx->d_key = nullptr; }
     ctx->plane_elems = 0;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_t, elems * sizeof(float)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_id, elems * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_key, elems * sizeof(unsigned long long)));
     ctx->plane_elems = elems;
     return MRT_OK;
 }
@@ -498,9 +535,19 @@ int ensure_out(mrt_ctx* ctx, size_t elems) {
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
-// Enqueue the frame (one launch, two for the tile cull) for this rank's rows on `stream`.
+// Where a frame's working planes come from: the ctx's own buffers, grown on demand, or
+// planes the caller brings (no allocation; t / id may then be absent).
+struct FramePlanes {
+    unsigned long long* key = nullptr;   // caller-provided key plane, or nullptr = the ctx's own
+    size_t key_capacity = 0;             // keys the caller's plane holds
+    bool want_tid = false;               // write the (t, id) planes (ctx-owned)
+    bool own = true;                     // the ctx may (re)allocate
+};
+
+// Enqueue the frame (one launch, two for the tile cull or a sliced trace) for this rank's rows
+// on `stream`.
 int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world, uint32_t* dev_out,
-                 hipStream_t stream, bool timed) {
+                 hipStream_t stream, bool timed, const FramePlanes& planes) {
     RenderParams p = ctx->params;
     p.band_rows = band_rows;
     p.rank = rank;
@@ -519,26 +566,60 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     }
     const uint32_t pitch = round_up(p.xres, mrt::kBlockTileX);
     const uint32_t prow = round_up(p.local_rows, mrt::kBlockTileY);
-    int rc = ensure_planes(ctx, (size_t)pitch * prow);
-    if (rc != MRT_OK) return rc;
+    const size_t plane_elems = (size_t)pitch * prow;
+
+    // A single band (one rank, or bands at least as tall as the image) is a run of consecutive
+    // image rows whatever its height; only interleaved bands constrain the block kernels.
+    const bool consecutive = world == 1 || band_rows >= p.yres;
+    // The block reject needs a lane's four rows to be consecutive image rows.
+    const bool block = (ctx->flags & MRT_FLAG_BLOCK_REJECT) && (consecutive || band_rows % 4 == 0);
+    const bool persp = ctx->projection == MRT_PROJ_PERSP;
+    const dim3 tb(mrt::kBlockThreads);
+    // The tile cull needs a wave tile's 32 rows to be consecutive image rows, and it has no
+    // exact-only mode of its own.
+    const bool full = (ctx->flags & MRT_FLAG_FULL_TEST) != 0;
+    const bool cull = !full && (ctx->flags & MRT_FLAG_SCREEN_CULL) && !(ctx->flags & MRT_FLAG_NO_PREFILTER) &&
+                      (consecutive || band_rows % mrt::kWaveTile == 0);
+    if (cull && !planes.own)
+        return fail(ctx, MRT_ERR_INVALID, "MRT_FLAG_SCREEN_CULL needs per-pixel planes of its own; not available without allocation");
+
+    // Working planes.  trace_kernel keeps the closest hit of every pixel in a 64-bit key plane;
+    // the tile cull hands (t, id) planes to shade_kernel; full_trace_kernel needs neither.
+    unsigned long long* d_key = nullptr;
+    float* d_t = nullptr;
+    int32_t* d_id = nullptr;
+    if (!full && !cull) {
+        if (planes.own) {
+            const int rc = ensure_keys(ctx, plane_elems);
+            if (rc != MRT_OK) return rc;
+            d_key = ctx->d_key;
+        } else {
+            if (plane_elems > planes.key_capacity)
+                return fail(ctx, MRT_ERR_TOO_LARGE,
+                            "this rank's rows, padded to 64x64 tiles, need " + std::to_string(plane_elems) +
+                                " closest-hit keys; the fixed array holds " + std::to_string(planes.key_capacity));
+            d_key = planes.key;
+        }
+    }
+    if (planes.want_tid || cull) {
+        const int rc = ensure_planes(ctx, plane_elems);
+        if (rc != MRT_OK) return rc;
+        d_t = ctx->d_t;
+        d_id = ctx->d_id;
+    }
+    // The planes are shared by all frames of this ctx: a frame on another stream waits for the last one.
+    if (planes.own && ctx->frame_pending && stream != ctx->last_stream)
+        HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->frame_done, 0));
     if (p.exact_counter) HIP_TRY(ctx, hipMemsetAsync(p.exact_counter, 0, sizeof(unsigned long long), stream));
 
     const dim3 tgrid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY);
     const dim3 fgrid(pitch / mrt::kBlockTileX, prow / 32);      // full_trace_kernel: blocks of 64 x 32 pixels
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
-    // The block reject needs a lane's four rows to be consecutive image rows.
-    const bool block = (ctx->flags & MRT_FLAG_BLOCK_REJECT) && (band_rows % 4 == 0);
-    const bool persp = ctx->projection == MRT_PROJ_PERSP;
-    const dim3 tb(mrt::kBlockThreads);
-    // The tile cull needs a wave tile's 32 rows to be consecutive image rows, and it has no
-    // exact-only mode of its own.
-    const bool cull = (ctx->flags & MRT_FLAG_SCREEN_CULL) && !(ctx->flags & MRT_FLAG_NO_PREFILTER) &&
-                      (band_rows % mrt::kWaveTile == 0);
     // trace_kernel and full_trace_kernel shade their own pixels in the epilogue (one launch per
     // frame); 16-byte stores need rows and buffer aligned to four pixels.  The tile cull runs at
     // low occupancy and leaves shading to shade_kernel.
-    const bool full = (ctx->flags & MRT_FLAG_FULL_TEST) != 0;
-    p.fuse_shade = (cull && !full) ? 0u : ((p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u);
+    const uint32_t fused = (p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u;
+    p.fuse_shade = cull ? 0u : fused;
     // trace_kernel takes the triangle list in slices, one grid layer each; the (t, id) keys merge
     // them.  A frame with few tiles needs that to fill the GPU at all (a wave alone on its SIMD
     // issues at a fraction of the rate six reach together); a 4K frame (8160 tiles) still gains
@@ -546,8 +627,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     // filling up and draining.  Target: about 128 K waves per launch; whole LDS chunks per slice.
     p.prim_slices = 1;
     p.slice_tris = p.n_tri_padded;
-    const bool sliced_path = !full && !cull;
-    if (sliced_path) {
+    if (!full && !cull) {
         const uint32_t waves = tgrid.x * tgrid.y * (mrt::kBlockThreads / 64);
         const uint32_t chunks = p.n_tri_padded / mrt::kChunkTris;
         const char* force = std::getenv("MRT_FORCE_SLICES");          // tuning aid
@@ -560,46 +640,61 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         }
     }
     const dim3 zgrid(tgrid.x, tgrid.y, p.prim_slices);
-    if (p.prim_slices > 1) {
-        p.fuse_shade = (p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_key, 0xFF, (size_t)pitch * prow * sizeof(unsigned long long), stream));
-    }
-    if ((ctx->flags & MRT_FLAG_FULL_TEST) && persp)
+    if (p.prim_slices > 1)
+        HIP_TRY(ctx, hipMemsetAsync(d_key, 0xFF, plane_elems * sizeof(unsigned long long), stream));
+    uint32_t kernel;
+    if (full && persp) {
+        kernel = MRT_KERNEL_FULL;
         hipLaunchKernelGGL((mrt::full_trace_kernel<MRT_PROJ_PERSP>), fgrid, tb, 0, stream, p,
-                           (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, ctx->d_t, ctx->d_id, pitch);
-    else if (ctx->flags & MRT_FLAG_FULL_TEST)
+                           (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, d_t, d_id, pitch);
+    } else if (full) {
+        kernel = MRT_KERNEL_FULL;
         hipLaunchKernelGGL((mrt::full_trace_kernel<MRT_PROJ_ORTHO>), fgrid, tb, 0, stream, p,
-                           (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, ctx->d_t, ctx->d_id, pitch);
-    else if (cull && persp)
-        hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_PERSP>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
-    else if (cull)
-        hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_ORTHO>), tgrid, tb, 0, stream, p, ctx->d_t, ctx->d_id, pitch);
-    else if (persp && block)
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true>), zgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
-    else if (persp)
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false>), zgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
-    else if (block)
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true>), zgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
-    else
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false>), zgrid, tb, 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
+                           (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, d_t, d_id, pitch);
+    } else if (cull && persp) {
+        kernel = MRT_KERNEL_CULL;
+        hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_PERSP>), tgrid, tb, 0, stream, p, d_t, d_id, pitch);
+    } else if (cull) {
+        kernel = MRT_KERNEL_CULL;
+        hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_ORTHO>), tgrid, tb, 0, stream, p, d_t, d_id, pitch);
+    } else if (persp && block) {
+        kernel = MRT_KERNEL_TRACE_BLOCK;
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+    } else if (persp) {
+        kernel = MRT_KERNEL_TRACE;
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+    } else if (block) {
+        kernel = MRT_KERNEL_TRACE_BLOCK;
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+    } else {
+        kernel = MRT_KERNEL_TRACE;
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     if (p.prim_slices > 1) {
         const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
         if (persp)
-            hipLaunchKernelGGL(mrt::shade_keys_kernel<MRT_PROJ_PERSP>, sgrid, dim3(256), 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
+            hipLaunchKernelGGL(mrt::shade_keys_kernel<MRT_PROJ_PERSP>, sgrid, dim3(256), 0, stream, p, d_key, d_t, d_id, pitch);
         else
-            hipLaunchKernelGGL(mrt::shade_keys_kernel<MRT_PROJ_ORTHO>, sgrid, dim3(256), 0, stream, p, ctx->d_key, ctx->d_t, ctx->d_id, pitch);
+            hipLaunchKernelGGL(mrt::shade_keys_kernel<MRT_PROJ_ORTHO>, sgrid, dim3(256), 0, stream, p, d_key, d_t, d_id, pitch);
         HIP_TRY(ctx, hipGetLastError());
     } else if (!p.fuse_shade) {
         const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
         if (persp)
-            hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_PERSP>, sgrid, dim3(256), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+            hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_PERSP>, sgrid, dim3(256), 0, stream, p, d_t, d_id, pitch);
         else
-            hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_ORTHO>, sgrid, dim3(256), 0, stream, p, ctx->d_t, ctx->d_id, pitch);
+            hipLaunchKernelGGL(mrt::shade_kernel<MRT_PROJ_ORTHO>, sgrid, dim3(256), 0, stream, p, d_t, d_id, pitch);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
+    ctx->last_kernel = kernel;
+    ctx->last_slices = p.prim_slices;
+    if (planes.own) {
+        HIP_TRY(ctx, hipEventRecord(ctx->frame_done, stream));
+        ctx->last_stream = stream;
+        ctx->frame_pending = true;
+    }
     return MRT_OK;
 }
 
@@ -615,6 +710,8 @@ int fill_stats(mrt_ctx* ctx, mrt_stats* st, uint32_t rows) {
     st->rays = (uint64_t)rows * ctx->params.xres;
     st->prim_tests = st->rays * ((uint64_t)ctx->params.n_sph + ctx->params.n_tri);
     st->exact_tests = 0;
+    st->kernel = ctx->last_kernel;
+    st->prim_slices = ctx->last_slices;
     if (ctx->flags & MRT_FLAG_COUNT_EXACT) {
         unsigned long long c = 0;
         HIP_TRY(ctx, hipMemcpy(&c, ctx->d_counter, sizeof c, hipMemcpyDeviceToHost));
@@ -655,10 +752,12 @@ int mrt_create(const mrt_config* cfg, mrt_ctx** out) {
         mrt_destroy(ctx);
         return fail(nullptr, MRT_ERR_HIP, msg);
     };
-    if ((e = hipSetDevice(dev)) != hipSuccess) return bail("hipSetDevice", e);
+    DeviceGuard guard(dev);
+    if (guard.err != hipSuccess) return bail("hipSetDevice", guard.err);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     for (int k = 0; k < 3; ++k)
         if ((e = hipEventCreate(&ctx->ev[k])) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->frame_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&ctx->d_counter, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     *out = ctx;
     return MRT_OK;
@@ -666,8 +765,9 @@ int mrt_create(const mrt_config* cfg, mrt_ctx** out) {
 
 void mrt_destroy(mrt_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DeviceGuard guard(ctx->device);
+    // Frames may be in flight on the caller's streams too.
+    (void)hipDeviceSynchronize();
     free_dev(ctx->d_sph_filter); free_dev(ctx->d_tri_filter); free_dev(ctx->d_tri_circle); free_dev(ctx->d_tri_exact); free_dev(ctx->d_full_rec); free_dev(ctx->d_sph);
     if (ctx->d_full_ids) (void)hipFree(ctx->d_full_ids);
     if (ctx->d_full_counts) (void)hipFree(ctx->d_full_counts);
@@ -678,6 +778,7 @@ void mrt_destroy(mrt_ctx* ctx) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     for (int k = 0; k < 3; ++k) if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    if (ctx->frame_done) (void)hipEventDestroy(ctx->frame_done);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -762,7 +863,10 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     if (!ctx) return MRT_ERR_INVALID;
     int rc = check_scene(ctx, s);
     if (rc != MRT_OK) return rc;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
+    // Frames already enqueued on any stream still read the buffers this call replaces.
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->frame_pending = false;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->have_scene = false;
 
@@ -842,9 +946,10 @@ int mrt_set_camera(mrt_ctx* ctx, const mrt_camera* cam) {
     if (cam->xres > 65536u || cam->yres > 65536u) return fail(ctx, MRT_ERR_TOO_LARGE, "resolution above 65536");
     if (cam->projection != MRT_PROJ_ORTHO && cam->projection != MRT_PROJ_PERSP)
         return fail(ctx, MRT_ERR_INVALID, "unknown projection");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     // Frames already enqueued on any stream still read the old records.
     HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->frame_pending = false;
     mrt_scene& h = ctx->h_scene;
     for (int k = 0; k < 3; ++k) { h.eye[k] = cam->eye[k]; h.u[k] = cam->u[k]; h.v[k] = cam->v[k]; h.w[k] = cam->w[k]; }
     h.xres = cam->xres; h.yres = cam->yres;
@@ -879,9 +984,9 @@ int mrt_render_bands_device(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uin
     if (need && !dev_out) return fail(ctx, MRT_ERR_INVALID, "dev_out is NULL");
     if (dev_out_bytes < need) return fail(ctx, MRT_ERR_INVALID, "dev_out too small for this rank's rows");
     if (((uintptr_t)dev_out & 3u) != 0) return fail(ctx, MRT_ERR_INVALID, "dev_out must be 4-byte aligned");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     hipStream_t stream = (hipStream_t)hip_stream;
-    int rc = launch_frame(ctx, band_rows, rank, world, (uint32_t*)dev_out, stream, stats != nullptr);
+    int rc = launch_frame(ctx, band_rows, rank, world, (uint32_t*)dev_out, stream, stats != nullptr, FramePlanes{});
     if (rc != MRT_OK) return rc;
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
@@ -895,12 +1000,14 @@ int mrt_render_debug(mrt_ctx* ctx, uint8_t* host_out, int32_t* ids, float* t, mr
     if (!ctx) return MRT_ERR_INVALID;
     if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
     if (!host_out && !ids && !t) return fail(ctx, MRT_ERR_INVALID, "no output requested");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     const uint32_t xres = ctx->params.xres, yres = ctx->params.yres;
     const size_t npx = (size_t)xres * yres;
     int rc = ensure_out(ctx, npx);
     if (rc != MRT_OK) return rc;
-    rc = launch_frame(ctx, yres, 0, 1, ctx->d_out, ctx->stream, true);
+    FramePlanes planes;
+    planes.want_tid = ids != nullptr || t != nullptr;
+    rc = launch_frame(ctx, yres, 0, 1, ctx->d_out, ctx->stream, true, planes);
     if (rc != MRT_OK) return rc;
     mrt_stats local;
     std::memset(&local, 0, sizeof local);

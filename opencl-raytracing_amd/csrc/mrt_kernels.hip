@@ -7,8 +7,8 @@
 // kernel's epilogue, shade_pixel rebuilds the winning hit record, shades it
 // (flat_shader / phong_shader, kernel.cl:381-445), converts to bytes
 // (gfximage.hpp:46-51) and writes coalesced RGBA8.  (t, object id) per pixel
-// are also written to two planes for callers that ask for them and for
-// shade_kernel, the separate shading launch cull_trace_kernel uses.
+// go to two planes only when the caller asks for them (t_out != nullptr) and
+// for shade_kernel, the separate shading launch cull_trace_kernel uses.
 //
 // Three kernels implement the closest-hit loop, selected by mrt_config.flags;
 // all give the same winners, t and bytes:
@@ -505,8 +505,10 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
             tv.y = iv.y < 0 ? -1.0f : __uint_as_float((uint32_t)(k01.y >> 32));
             tv.z = iv.z < 0 ? -1.0f : __uint_as_float((uint32_t)(k23.x >> 32));
             tv.w = iv.w < 0 ? -1.0f : __uint_as_float((uint32_t)(k23.y >> 32));
-            *reinterpret_cast<float4*>(t_out + off) = tv;
-            *reinterpret_cast<int4*>(id_out + off) = iv;
+            if (t_out != nullptr) {         // the (t, id) planes are written only for callers that ask
+                *reinterpret_cast<float4*>(t_out + off) = tv;
+                *reinterpret_cast<int4*>(id_out + off) = iv;
+            }
             // Shade this row segment here rather than in a second launch: four pixels, one
             // aligned 16-byte RGBA8 store per lane, 128 contiguous bytes per lane row of the wave.
             if (p.fuse_shade) shade_row4<PROJ>(p, x0, lr0 + j, tv, iv);
@@ -1010,8 +1012,10 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
             tv.y = iv.y < 0 ? -1.0f : best_t[j * 4 + 1];
             tv.z = iv.z < 0 ? -1.0f : best_t[j * 4 + 2];
             tv.w = iv.w < 0 ? -1.0f : best_t[j * 4 + 3];
-            *reinterpret_cast<float4*>(t_out + off) = tv;
-            *reinterpret_cast<int4*>(id_out + off) = iv;
+            if (t_out != nullptr) {
+                *reinterpret_cast<float4*>(t_out + off) = tv;
+                *reinterpret_cast<int4*>(id_out + off) = iv;
+            }
             if (p.fuse_shade) shade_row4<PROJ>(p, x0, lr0 + j, tv, iv);
         }
         if (p.exact_counter != nullptr)
@@ -1020,7 +1024,7 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
 }
 
 // The epilogue of trace_kernel as a launch of its own, for frames traced in several slices: one
-// thread per pixel decodes the key, writes the (t, id) planes and shades.  A key the host's
+// thread per pixel decodes the key, writes the (t, id) planes if asked to, and shades.  A key the host's
 // byte-wise initialisation left untouched is all ones: id -1, a miss.
 template <int PROJ>
 __global__ __launch_bounds__(256) void shade_keys_kernel(const RenderParams p,
@@ -1034,8 +1038,10 @@ __global__ __launch_bounds__(256) void shade_keys_kernel(const RenderParams p,
     const unsigned long long key = key_plane[src];
     const int32_t id = (int32_t)(uint32_t)key;
     const float t = id < 0 ? -1.0f : __uint_as_float((uint32_t)(key >> 32));     // kernel.cl:363
-    t_out[src] = t;
-    id_out[src] = id;
+    if (t_out != nullptr) {
+        t_out[src] = t;
+        id_out[src] = id;
+    }
     p.out[(size_t)lr * p.xres + x] = shade_pixel<PROJ>(p, x, image_row(p, lr), t, id);
 }
 

@@ -155,6 +155,17 @@ struct DevBuf {
             return mrt_stage_set_error_(ctx, MRT_ERR_HIP, (std::string(#expr) + ": " + hipGetErrorString(e_)).c_str()); \
     } while (0)
 
+// Puts the caller's current HIP device back when a stage call returns (begin() below switches
+// to the ctx's GPU).
+struct RestoreDevice {
+    int prev = -1;
+    RestoreDevice() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~RestoreDevice() {
+        int now = -1;
+        if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev);
+    }
+};
+
 int begin(mrt_ctx* ctx, int n, const void* a, const void* b) {
     if (!ctx) return MRT_ERR_INVALID;
     if (n < 0) return mrt_stage_set_error_(ctx, MRT_ERR_INVALID, "negative element count");
@@ -174,6 +185,7 @@ mrt::CamK cam_of(const mrt_cl_cam* c) {
 
 int rays_common(mrt_ctx* ctx, const mrt_cl_cam* camera, const mrt_cl_float2* uv, int n, float focal,
                 mrt_cl_ray* rays_out, bool persp) {
+    RestoreDevice restore_device;
     int rc = begin(ctx, n, uv, rays_out);
     if (rc != MRT_OK) return rc;
     if (!camera) return mrt_stage_set_error_(ctx, MRT_ERR_INVALID, "camera is NULL");
@@ -204,6 +216,7 @@ int rays_common(mrt_ctx* ctx, const mrt_cl_cam* camera, const mrt_cl_float2* uv,
 int shade_common(mrt_ctx* ctx, const mrt_cl_intersect* xsects, int n, mrt_cl_rgb background,
                  const mrt_cl_phong* phong, const mrt_cl_cam* camera, const mrt_cl_light* lights,
                  int n_lights, mrt_cl_rgb* out, bool flat) {
+    RestoreDevice restore_device;
     int rc = begin(ctx, n, xsects, out);
     if (rc != MRT_OK) return rc;
     if (!flat && (!phong || !camera || n_lights < 0 || (n_lights > 0 && !lights)))
@@ -251,6 +264,7 @@ extern "C" {
 
 int mrt_stage_uv(mrt_ctx* ctx, const mrt_cl_float3* positions, const mrt_cl_vp* viewport, int n,
                  mrt_cl_float2* uv_out) {
+    RestoreDevice restore_device;
     int rc = begin(ctx, n, positions, uv_out);
     if (rc != MRT_OK) return rc;
     if (!viewport) return mrt_stage_set_error_(ctx, MRT_ERR_INVALID, "viewport is NULL");
@@ -279,6 +293,7 @@ int mrt_stage_persp_viewrays(mrt_ctx* ctx, const mrt_cl_cam* camera, const mrt_c
 
 int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_objects, const mrt_cl_ray* rays,
                         int n_rays, float t_upper_bound, float t_lower_bound, mrt_cl_intersect* out) {
+    RestoreDevice restore_device;
     int rc = begin(ctx, n_rays, rays, out);
     if (rc != MRT_OK) return rc;
     if (n_objects < 0 || (n_objects > 0 && !objects))

@@ -50,49 +50,70 @@ def main(argv):
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    def all_ok(ok):
+        """True when every rank got this far without an error: agreed on before each collective, so
+        that a rank that failed never leaves the others waiting inside a gather."""
+        if world == 1:
+            return ok
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device="cpu" if rehearsal else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return int(flag.item()) == 0
+
     status = 0
+    ctx = None
     try:
+        scene, load_err = None, None
         try:
             scene = mrt.LoadedScene(path=scene_path)          # every rank parses the file itself
         except mrt.MrtError as e:
+            load_err = e.message
+        if not all_ok(load_err is None):
             if rank == 0:
-                print(f'error loading scene "{scene_path}": {e.message}', file=sys.stderr)
+                print(f'error loading scene "{scene_path}": {load_err or "another rank could not load it"}',
+                      file=sys.stderr)
             return 1
         st = scene.struct
         if rank == 0:
             print("raytracing...", end="", flush=True)
-        ctx = mrt.Context(device=dev_index, flags=int(os.environ.get("MRT_FLAGS", "0"), 0))
+        rows = [mrt.band_rows(st.yres, BAND_ROWS, r, world) for r in range(world)]
+        stride = max(max(rows) * st.xres * 4, 4)
+        local, render_err = None, None
         try:
+            ctx = mrt.Context(device=dev_index, flags=int(os.environ.get("MRT_FLAGS", "0"), 0))
             ctx.set_scene(scene)
-            rows = [mrt.band_rows(st.yres, BAND_ROWS, r, world) for r in range(world)]
-            stride = max(max(rows) * st.xres * 4, 4)
             local = torch.empty(stride, dtype=torch.uint8, device=dev)
             ctx.render_bands_device(BAND_ROWS, rank, world, local.data_ptr(), local.numel(),
                                     stream=torch.cuda.current_stream(dev).cuda_stream)
-            if world == 1:
-                gathered = local.cpu().numpy().reshape(1, stride)
-            elif rehearsal:
-                parts = [torch.empty(stride, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
-                dist.gather(local.cpu(), parts, dst=0)
-                gathered = torch.stack(parts).numpy() if rank == 0 else None
-            else:
-                parts = [torch.empty(stride, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-                dist.gather(local, parts, dst=0)              # RCCL over xGMI
-                gathered = torch.stack(parts).cpu().numpy() if rank == 0 else None
-        finally:
-            ctx.close()
+            torch.cuda.synchronize(dev)
+        except mrt.MrtError as e:
+            render_err = e.message
+        if not all_ok(render_err is None):                    # nobody enters the gather
+            print(f"\nerror: render failed on rank {rank}: {render_err or 'another rank failed'}", file=sys.stderr)
+            return 1
+        if world == 1:
+            gathered = local.cpu().numpy().reshape(1, stride)
+        elif rehearsal:
+            parts = [torch.empty(stride, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+            dist.gather(local.cpu(), parts, dst=0)
+            gathered = torch.stack(parts).numpy() if rank == 0 else None
+        else:
+            parts = [torch.empty(stride, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(local, parts, dst=0)                  # RCCL over xGMI
+            gathered = torch.stack(parts).cpu().numpy() if rank == 0 else None
         if rank == 0:
             print("done", flush=True)
             image = mrt.bands_to_image(gathered, stride, st.xres, st.yres, BAND_ROWS, world)
             print(f"writing {png_path}...", end="", flush=True)
-            mrt.write_png_rgb(png_path, image)
-            print("done\n", flush=True)
-    except mrt.MrtError as e:
-        print(f"\nerror: render failed: {e.message}", file=sys.stderr)
-        status = 1
+            try:
+                mrt.write_png_rgb(png_path, image)
+                print("done\n", flush=True)
+            except mrt.MrtError:
+                print("\nerror: could not write PNG", file=sys.stderr)
+                status = 1
     finally:
+        if ctx is not None:
+            ctx.close()
         if world > 1:
-            dist.barrier()
             dist.destroy_process_group()
     return status
 

@@ -31,7 +31,8 @@ def camera_basis(view, up):
     return u, v, w
 
 
-def scene_from_dict(j, xres=None, yres=None, viewport=None):
+def scene_from_dict(j, xres=None, yres=None, viewport=None, projection=None):
+    """xres / yres / viewport (left, right, top, bottom) / projection ("ortho" | "persp") override the file's."""
     eye = [float(x) for x in j["camera_eye"]]
     u, v, w = camera_basis([float(x) for x in j["camera_view"]], [float(x) for x in j["camera_up"]])
     mats = j["materials"]
@@ -55,8 +56,9 @@ def scene_from_dict(j, xres=None, yres=None, viewport=None):
         eye=eye, u=u, v=v, w=w,
         xres=j["x_resolution"] if xres is None else xres, yres=j["y_resolution"] if yres is None else yres,
         left=left, right=right, top=top, bottom=bottom,
-        projection=mrt.PROJ_ORTHO if "ortho_projection" in j else mrt.PROJ_PERSP,
-        focal=j.get("persp_focal_length", 0.0),
+        projection=((mrt.PROJ_ORTHO if "ortho_projection" in j else mrt.PROJ_PERSP) if projection is None
+                    else {"ortho": mrt.PROJ_ORTHO, "persp": mrt.PROJ_PERSP}[projection]),
+        focal=j.get("persp_focal_length", 1.0 if projection == "persp" else 0.0),
         shader=mrt.SHADER_FLAT if flat else mrt.SHADER_PHONG,
         ka=0.0 if flat else ph["ambient_coeff"], kd=0.0 if flat else ph["diffuse_coeff"],
         ks=0.0 if flat else ph["specular_coeff"],

@@ -16,16 +16,20 @@ from __future__ import annotations
 import numpy as np
 
 
-def render(scene, chunk=32):
+def render(scene, chunk=32, rows=None):
+    """rows=(y0, y1): render only image rows y0 .. y1-1 (the arrays returned then have y1 - y0
+    rows); the full frame otherwise."""
     st = scene.struct
-    w, h = st.xres, st.yres
+    w, full_h = st.xres, st.yres
+    y0, y1 = (0, full_h) if rows is None else rows
+    h = y1 - y0
     f64 = np.float64
     eye = np.array(list(st.eye), f64)
     cu, cv, cw = (np.array(list(v), f64) for v in (st.u, st.v, st.w))
     px = np.arange(w, dtype=f64) + 1.0          # pixel grid, gfxraytrace.hpp:850-852
-    py = np.arange(h, dtype=f64) + 1.0
+    py = np.arange(y0, y1, dtype=f64) + 1.0
     ux = f64(st.left) + (f64(st.right) - f64(st.left)) * (px + 0.5) / w      # kernel.cl:126
-    uy = f64(st.bottom) + (f64(st.top) - f64(st.bottom)) * (py + 0.5) / h    # kernel.cl:127
+    uy = f64(st.bottom) + (f64(st.top) - f64(st.bottom)) * (py + 0.5) / full_h    # kernel.cl:127
     UX, UY = np.meshgrid(ux, uy)                # [h, w]
     n = w * h
     UX = UX.reshape(n, 1)

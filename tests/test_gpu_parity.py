@@ -127,15 +127,19 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
             assert_same_hits(ra, rb)
             assert np.array_equal(ra["rgba"], rb["rgba"])
             assert rb["stats"].exact_tests == ra["stats"].exact_tests     # same survivors reach the exact test
+            # a whole frame is consecutive rows whatever its height: the flags get the kernel they ask for
+            assert ra["stats"].kernel == mrt.KERNEL_TRACE and rb["stats"].kernel == mrt.KERNEL_TRACE_BLOCK
             rc = gpu_render(c, sc)                                        # without the bounding-circle level
             assert_same_hits(ra, rc)
             assert np.array_equal(ra["rgba"], rc["rgba"])
             assert rc["stats"].exact_tests == ra["stats"].exact_tests
             rd = gpu_render(d, sc)                                        # opt-in tile culling
+            assert rd["stats"].kernel == mrt.KERNEL_CULL
             assert_same_hits(ra, rd)
             assert np.array_equal(ra["rgba"], rd["rgba"])
             assert rd["stats"].exact_tests <= ra["stats"].exact_tests * 1.01 + 64
             re_ = gpu_render(e, sc)                                       # determinants for every pair
+            assert re_["stats"].kernel == mrt.KERNEL_FULL
             assert_same_hits(ra, re_)
             assert np.array_equal(ra["rgba"], re_["rgba"])
             assert re_["stats"].exact_tests >= sc.struct.xres * sc.struct.yres * sc.n_objects
@@ -147,7 +151,8 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
         stride = max(rows) * 1280 * 4
         g = torch.zeros((2, stride), dtype=torch.uint8, device="cuda:0")
         for r in range(2):
-            b.render_bands_device(6, r, 2, g[r].data_ptr(), stride)
+            st6 = b.render_bands_device(6, r, 2, g[r].data_ptr(), stride, timed=True)
+            assert st6.kernel == mrt.KERNEL_TRACE          # stepped aside
         torch.cuda.synchronize()
         assert np.array_equal(mrt.bands_to_image(g.cpu().numpy(), stride, 1280, 720, 6, 2), full)
         # the tile cull needs 32 consecutive rows: bands of 32 use it, bands of 6 fall back
@@ -157,7 +162,8 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
             stride = max(rows) * 1280 * 4
             g = torch.zeros((3, stride), dtype=torch.uint8, device="cuda:0")
             for r in range(3):
-                d.render_bands_device(band, r, 3, g[r].data_ptr(), stride)
+                stb = d.render_bands_device(band, r, 3, g[r].data_ptr(), stride, timed=True)
+                assert stb.kernel == (mrt.KERNEL_CULL if band == 32 else mrt.KERNEL_TRACE)
             torch.cuda.synchronize()
             assert np.array_equal(mrt.bands_to_image(g.cpu().numpy(), stride, 1280, 720, band, 3), full)
         e.set_scene(sc)
@@ -289,8 +295,18 @@ def test_negative_zero_barycentric_is_a_hit(mrt, oracle):
                 r = gpu_render(ctx, sc)
             finally:
                 ctx.close()
+            assert r["stats"].kernel == _expected_kernel(mrt, flags)       # also on a 4 x 2 frame
             assert_same_hits(r, o)
             assert np.array_equal(r["rgba"], o["rgba"])
+
+
+def _expected_kernel(mrt, flags):
+    """The kernel a whole-frame render runs for these ctx flags."""
+    if flags & mrt.FLAG_FULL_TEST:
+        return mrt.KERNEL_FULL
+    if flags & mrt.FLAG_SCREEN_CULL and not flags & mrt.FLAG_NO_PREFILTER:
+        return mrt.KERNEL_CULL
+    return mrt.KERNEL_TRACE_BLOCK if flags & mrt.FLAG_BLOCK_REJECT else mrt.KERNEL_TRACE
 
 
 def test_non_finite_and_odd_inputs(mrt, oracle):
@@ -325,6 +341,7 @@ def test_non_finite_and_odd_inputs(mrt, oracle):
                 r = gpu_render(ctx, sc)
             finally:
                 ctx.close()
+            assert r["stats"].kernel == _expected_kernel(mrt, flags)
             assert_same_hits(r, o)
             check(r["rgba"], o["rgba"], o["ids"])
 
@@ -355,6 +372,7 @@ def test_equal_t_goes_to_the_lower_object_id(mrt, oracle):
                     r = gpu_render(ctx, sc)
                 finally:
                     ctx.close()
+                assert r["stats"].kernel == _expected_kernel(mrt, flags)
                 assert_same_hits(r, o)
                 assert np.array_equal(r["rgba"], o["rgba"])
 
@@ -417,6 +435,7 @@ def test_teatime_4k_full_frame_against_oracle(gpu_ctx, mrt, oracle):
             r2 = gpu_render(ctx, ls)
         finally:
             ctx.close()
+        assert r2["stats"].kernel == _expected_kernel(mrt, flags)          # 2160 rows: no multiple of 32
         assert_same_hits(r2, o)
         assert np.array_equal(r2["rgba"], r["rgba"])
 
@@ -525,6 +544,42 @@ def test_band_partition_invariance(gpu_ctx, mrt, world, band):
     torch.cuda.synchronize()
     img = mrt.bands_to_image(gathered.cpu().numpy(), stride, xres, yres, band, world)
     assert np.array_equal(img, full)
+
+
+def test_teatime_8k_banded_against_oracle(mrt, oracle):
+    """teatime at 7680 x 4320 cut into interleaved 64-row bands for 2, 4 and 8 ranks (each rank's
+    bands rendered into its own device buffer, one rank after the other on this one GPU, then put
+    back together on the host) must equal the single-launch frame pixel for pixel, and sampled
+    rows of that frame must carry the oracle's winners, t and colours."""
+    import torch
+    xres, yres, band = 7680, 4320, 64
+    sc = mrt.LoadedScene(text=mkscene.teatime(xres, yres)).copy()
+    ctx = mrt.Context(device=0)
+    try:
+        ctx.set_scene(sc)
+        full, ids, t, st = ctx.render(want_ids=True)
+        assert st.rays == xres * yres
+        for y in (0, 1300, 1777, 2160, 2500, 3071, 4319):
+            o = oracle.render(sc, rows=(y, y + 1), threads=16)
+            assert np.array_equal(ids[y], o["ids"][y])
+            assert np.array_equal(t[y], o["t"][y])
+            check(full[y:y + 1], o["rgba"][y:y + 1], o["ids"][y:y + 1])
+        assert (ids >= 0).sum() > 1200000
+        del ids, t
+        for world in (2, 4, 8):
+            rows = [mrt.band_rows(yres, band, r, world) for r in range(world)]
+            assert sum(rows) == yres
+            stride = max(rows) * xres * 4
+            gathered = torch.zeros((world, stride), dtype=torch.uint8, device="cuda:0")
+            for r in range(world):
+                ctx.render_bands_device(band, r, world, gathered[r].data_ptr(), stride,
+                                        stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            img = mrt.bands_to_image(gathered.cpu().numpy(), stride, xres, yres, band, world)
+            assert np.array_equal(img, full), world
+            del gathered, img
+    finally:
+        ctx.close()
 
 
 def test_api_errors(mrt):

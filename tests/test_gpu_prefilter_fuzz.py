@@ -101,9 +101,11 @@ def test_prefilters_never_drop_an_exact_hit(mrt, kind):
             sc = _scene(mrt, rng, kind, proj)
             exact.set_scene(sc)
             _, ids_e, t_e, _ = exact.render(want_ids=True)
-            for ctx in (fast, blk, cull, full):
+            for ctx, kernel in ((fast, mrt.KERNEL_TRACE), (blk, mrt.KERNEL_TRACE_BLOCK), (cull, mrt.KERNEL_CULL),
+                                (full, mrt.KERNEL_FULL)):
                 ctx.set_scene(sc)
-                _, ids_f, t_f, _ = ctx.render(want_ids=True)
+                _, ids_f, t_f, st_f = ctx.render(want_ids=True)
+                assert st_f.kernel == kernel       # any frame height gets the kernel its flags ask for
                 bad = int((ids_f != ids_e).sum())
                 assert bad == 0, (kind, it, proj, bad)
                 assert np.array_equal(t_f.view(np.uint32), t_e.view(np.uint32)), (kind, it, proj)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(mrt):
     header = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "mrt.h").read_text(), flags=re.S)
     declared = set(re.findall(r"\b(mrt_[a-z0-9_]+)\s*\(", header))
     assert declared == set(mrt.EXPORTED_SYMBOLS)
-    assert L.mrt_abi_version() == 1
+    assert L.mrt_abi_version() == mrt.ABI_VERSION
 
 
 def test_struct_sizes_match_reference_layout(mrt):

@@ -86,6 +86,19 @@ def test_phong_kat(oracle):
     assert abs(r["t"][200, 99] - t) < 1e-6
 
 
+def test_informational_reference_values(oracle):
+    """The only numbers that ever came out of the reference itself (seen in exploratory runs before
+    executing its code was ruled out; informational, not authoritative): 31 428 hit pixels for the
+    two orthographic half-discs, 9 924 under the perspective camera, and the float colour
+    (1, 0.430362, 0.430362) at pixel x = 99, y = 200 of scene_2spheres_persp_phong."""
+    assert int((oracle.render(load("scene_2spheres_ortho_flat"))["ids"] >= 0).sum()) == 31428
+    assert int((oracle.render(load("scene_2spheres_ortho_phong"))["ids"] >= 0).sum()) == 31428
+    assert int((oracle.render(load("scene_2spheres_persp_flat"))["ids"] >= 0).sum()) == 9924
+    r = oracle.render(load("scene_2spheres_persp_phong"), want_rgbf=True)
+    assert int((r["ids"] >= 0).sum()) == 9924
+    assert np.allclose(r["rgbf"][200, 99], [1.0, 0.430362, 0.430362], rtol=0, atol=5e-7)
+
+
 def test_sphere_near_root_only(oracle, mrt):
     # camera inside a sphere: the near root is negative, so it is a miss (kernel.cl:262-281)
     sc = mrt.Scene(eye=[0, 0, 0], u=[1, 0, 0], v=[0, -1, 0], w=[0, 0, -1], xres=8, yres=8, left=-1, right=1,
@@ -148,6 +161,35 @@ def test_oracle_agrees_with_float64_model_teatime_crop(oracle):
     s = specmodel.render(sc, chunk=32)
     check(s["rgba"], r["rgba"], r["ids"])
     assert (r["ids"] != s["ids"]).sum() <= 0.001 * r["ids"].size
+
+
+def test_oracle_vs_float64_model_on_benchmark_workloads(oracle):
+    """oracle/crosscheck.py compared the two restatements on the benchmark workloads (native
+    teatime in full, rows of the 4K teatime frame, the soup and both scenes under the orthographic
+    camera) and recorded the disagreements in tests/golden/oracle_vs_specmodel.json.  The record must
+    show agreement (winner mismatches only at the FP32-vs-FP64 edge level, no pixel beyond 1 LSB
+    off a primitive edge), and two of its sampled rows are recomputed here to hold it to account."""
+    import json
+    import crosscheck
+    rec = json.loads((GOLDEN / "oracle_vs_specmodel.json").read_text())
+    assert set(rec) >= {"teatime_400x400_all_rows", "teatime_3840x2160_rows", "teatime_ortho_640x320_rows",
+                        "soup_1024x1024_rows", "soup_ortho_1024x1024_rows"}
+    for name, r in rec.items():
+        assert r["hit_pixels"] > 0.03 * r["pixels"], name
+        assert r["id_mismatches"] <= 0.0005 * r["pixels"], name
+        # FP32 vs FP64 colours part by more than 1 LSB only where FP32 is ill-conditioned: at primitive
+        # edges and on the limbs of the soup's few-pixel spheres under the orthographic camera, where
+        # b*b - a*c (kernel.cl:254) cancels to 1e-2 relative and moves t, hence the normal
+        assert r["beyond_1lsb"] <= 0.002 * r["pixels"], name
+        assert r["beyond_1lsb_off_edge"] <= (2e-4 * r["pixels"] if "soup_ortho" in name else 0), name
+        assert r["max_rel_t_diff_same_winner"] < 1e-3, name
+    for name, sc, rows in crosscheck.cases():
+        if name not in ("teatime_3840x2160_rows", "soup_1024x1024_rows"):
+            continue
+        again = crosscheck.compare(sc, rows[3:5], threads=4)
+        assert again["beyond_1lsb_off_edge"] == 0
+        assert again["id_mismatches"] <= rec[name]["id_mismatches"]
+        assert again["beyond_1lsb"] <= rec[name]["beyond_1lsb"]
 
 
 def test_threads_and_row_ranges_are_invariant(oracle):
