@@ -224,6 +224,25 @@ int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uin
                             void *dev_out, size_t dev_out_bytes, void *hip_stream,
                             mrt_stats *stats);
 
+/* mrt_render_bands_device for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc): same arguments without stats, same pixels, but the closest-hit
+ * key plane the trace kernel works in lives in a fixed array inside the
+ * library instead of a buffer the ctx grows on demand, and the call makes no
+ * hipMalloc / hipFree (nor any other allocating call).  The array holds
+ * MRT_NOALLOC_MAX_KEYS 64-bit keys (64 MiB on every GPU the library has been
+ * used on, until the process ends): the rows this rank renders, padded to
+ * whole 64x64 pixel tiles, must fit -- a 3840x2160 frame does -- or the call
+ * fails with MRT_ERR_TOO_LARGE.  Contexts created with MRT_FLAG_SCREEN_CULL
+ * are refused (that kernel needs per-pixel planes of its own).  Every call on
+ * one GPU, from whatever ctx, shares that GPU's array: two such frames in
+ * flight at once on one GPU race; enqueue them on one stream or synchronise
+ * between them.  No counterpart in the reference, which allocates in every
+ * stage call (CLHelpers.hpp:93-104). */
+#define MRT_NOALLOC_MAX_KEYS (8u * 1024u * 1024u)
+int mrt_render_bands_device_noalloc(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uint32_t world,
+                                    void *dev_out, size_t dev_out_bytes, void *hip_stream);
+
 /* Host-side inverse of the band partition: scatter the gathered per-rank
  * buffers (rank r's bytes start at gathered + r*stride_bytes) into a
  * scanline-ordered xres*yres RGBA8 image. */

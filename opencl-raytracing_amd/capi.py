@@ -35,7 +35,9 @@ EXPORTED_SYMBOLS = [
     "mrt_scene_info_view", "mrt_scene_free", "mrt_write_png_rgb", "mrt_stage_uv",
     "mrt_stage_ortho_viewrays", "mrt_stage_persp_viewrays", "mrt_stage_intersect",
     "mrt_stage_flat_shader", "mrt_stage_phong_shader", "mrt_host_alloc", "mrt_host_free",
+    "mrt_render_bands_device_noalloc",
 ]
+NOALLOC_MAX_KEYS = 8 * 1024 * 1024
 
 _fp = C.POINTER(C.c_float)
 _up = C.POINTER(C.c_uint32)
@@ -173,6 +175,7 @@ def lib():
     L.mrt_band_rows.restype = C.c_uint32
     L.mrt_render_bands_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp,
                                           C.POINTER(Stats)]
+    L.mrt_render_bands_device_noalloc.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
     L.mrt_bands_to_image.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.mrt_scene_load_file.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.mrt_scene_load_text.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp), C.c_char_p, C.c_size_t]
@@ -355,6 +358,10 @@ class Context:
         self._check(lib().mrt_render_bands_device(self._h, band_rows_, rank, world, dev_ptr, nbytes,
                                                   stream or None, C.byref(stats) if timed else None))
         return stats
+
+    def render_bands_device_noalloc(self, band_rows_, rank, world, dev_ptr, nbytes, stream=0):
+        self._check(lib().mrt_render_bands_device_noalloc(self._h, band_rows_, rank, world, dev_ptr, nbytes,
+                                                          stream or None))
 
     # stage-level entry points on numpy structured arrays (CL_DTYPES)
     def stage_uv(self, pos, vp):

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,36 @@ __global__ void shade_keys_kernel(const RenderParams p, const unsigned long long
 }  // namespace mrt
 
 using mrt::RenderParams;
+
+// Fixed working memory of mrt_render_bands_device_noalloc: the closest-hit key plane of one frame
+// (MRT_NOALLOC_MAX_KEYS 64-bit keys, 64 MiB).  Every GPU the library runs on holds its own copy
+// of the array at its own address until the process ends.  In host code the array's name is only
+// a handle: the device address comes from hipGetSymbolAddress, once per device with that device
+// current (scratch_address below), and that pointer -- never the name -- is what kernels, memsets
+// and copies are given.
+static __device__ __align__(256) unsigned long long scratch[MRT_NOALLOC_MAX_KEYS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned long long* g_scratch_ptr[kMaxDevices] = {};
+
+// Device address of this device's copy of `scratch`; `device` must be the current device.
+hipError_t scratch_address(int device, unsigned long long** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = static_cast<unsigned long long*>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+}  // namespace
 
 struct mrt_ctx {
     int device = 0;
@@ -79,6 +110,7 @@ struct mrt_ctx {
     uint32_t* d_out = nullptr;
     size_t out_elems = 0;
     unsigned long long* d_counter = nullptr;
+    unsigned long long* scratch_keys = nullptr;   // this device's copy of `scratch` (not owned)
 
     // The last frame enqueued: which kernel it ran, and an event behind it so that a frame on
     // another stream can be ordered after it (the working planes above are shared by all frames).
@@ -759,6 +791,7 @@ int mrt_create(const mrt_config* cfg, mrt_ctx** out) {
         if ((e = hipEventCreate(&ctx->ev[k])) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->frame_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&ctx->d_counter, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = scratch_address(dev, &ctx->scratch_keys)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     *out = ctx;
     return MRT_OK;
 }
@@ -994,6 +1027,27 @@ int mrt_render_bands_device(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uin
         rc = fill_stats(ctx, stats, rows);
     }
     return rc;
+}
+
+int mrt_render_bands_device_noalloc(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world,
+                                    void* dev_out, size_t dev_out_bytes, void* hip_stream) {
+    if (!ctx) return MRT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
+    if (band_rows == 0 || world == 0 || rank >= world) return fail(ctx, MRT_ERR_INVALID, "bad band partition");
+    const uint32_t rows = mrt_band_rows(ctx->params.yres, band_rows, rank, world);
+    const size_t need = (size_t)rows * ctx->params.xres * 4;
+    if (need && !dev_out) return fail(ctx, MRT_ERR_INVALID, "dev_out is NULL");
+    if (dev_out_bytes < need) return fail(ctx, MRT_ERR_INVALID, "dev_out too small for this rank's rows");
+    if (((uintptr_t)dev_out & 3u) != 0) return fail(ctx, MRT_ERR_INVALID, "dev_out must be 4-byte aligned");
+    ENTER_DEVICE(ctx);
+    // The key plane is this GPU's copy of the fixed array, shared by every such call on the GPU and
+    // holding whatever the last one left: launch_frame clears the part this frame uses (a memset
+    // for a sliced frame, the kernel's prologue otherwise) and never allocates in this mode.
+    FramePlanes planes;
+    planes.own = false;
+    planes.key = ctx->scratch_keys;
+    planes.key_capacity = MRT_NOALLOC_MAX_KEYS;
+    return launch_frame(ctx, band_rows, rank, world, (uint32_t*)dev_out, (hipStream_t)hip_stream, false, planes);
 }
 
 int mrt_render_debug(mrt_ctx* ctx, uint8_t* host_out, int32_t* ids, float* t, mrt_stats* stats) {
