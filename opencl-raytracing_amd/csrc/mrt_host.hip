@@ -838,18 +838,24 @@ static int rebuild_view(mrt_ctx* ctx) {
     p.xres_f = (float)s->xres; p.yres_f = (float)s->yres;
     p.focal = s->focal;
     {
-        // Largest |component| a primary-ray direction can have (persp_viewrays, kernel.cl:140-147:
-        // -w f + u uv.x + v uv.y; the orthographic direction is -w), with room for rounding.
-        auto amax = [](const float* a) { return std::fmax(std::fabs((double)a[0]), std::fmax(std::fabs((double)a[1]), std::fabs((double)a[2]))); };
-        // uv of the last pixel lies half a pixel beyond the viewport edge (kernel.cl:126-127)
+        // Per component, the largest magnitude a primary-ray direction and origin can have
+        // (persp_viewrays, kernel.cl:140-147: origin eye, direction -w f + u uv.x + v uv.y;
+        // ortho_viewrays, :130-138: origin u uv.x + v uv.y, direction -w), with room for
+        // rounding.  uv of the last pixel lies half a pixel beyond the viewport edge
+        // (kernel.cl:126-127); one whole pixel is allowed for here.
         const double mux = std::fmax(std::fabs((double)s->left), std::fabs((double)s->right)) +
                            std::fabs((double)s->right - (double)s->left) / s->xres;
         const double muy = std::fmax(std::fabs((double)s->top), std::fabs((double)s->bottom)) +
                            std::fabs((double)s->top - (double)s->bottom) / s->yres;
-        const double dmax = s->projection == MRT_PROJ_PERSP
-                                ? std::fabs((double)s->focal) * amax(s->w) + mux * amax(s->u) + muy * amax(s->v)
-                                : amax(s->w);
-        p.ray_absmax = (float)(dmax * 1.01);
+        for (int k = 0; k < 3; ++k) {
+            const double span = mux * std::fabs((double)s->u[k]) + muy * std::fabs((double)s->v[k]);
+            const double dir = s->projection == MRT_PROJ_PERSP
+                                   ? std::fabs((double)s->focal) * std::fabs((double)s->w[k]) + span
+                                   : std::fabs((double)s->w[k]);
+            const double org = s->projection == MRT_PROJ_PERSP ? std::fabs((double)s->eye[k]) : span;
+            p.ray_abs[k] = (float)(dir * 1.01);
+            p.org_abs[k] = (float)(org * 1.01);
+        }
     }
     p.xres = s->xres; p.yres = s->yres;
     p.n_tri_padded = (uint32_t)(filt.size() / 3);
@@ -864,7 +870,7 @@ static int rebuild_view(mrt_ctx* ctx) {
         // roundings.  One chunk of slack: the kernel stages whole LDS chunks from wherever a sign
         // group starts (it never tests what lies beyond the group).
         const size_t n_rec = (size_t)round_up(s->n_tris ? s->n_tris : 1, mrt::kChunkTris) + mrt::kChunkTris;
-        const size_t bytes = n_rec * 3 * sizeof(float4);
+        const size_t bytes = n_rec * mrt::kFullRecFloat4 * sizeof(float4);
         if (!ctx->d_full_rec || ctx->cap_full_rec != bytes) {
             free_dev(ctx->d_full_rec);
             if (ctx->d_full_ids) { (void)hipFree(ctx->d_full_ids); ctx->d_full_ids = nullptr; }

@@ -22,8 +22,8 @@
 //                      survive run the reference arithmetic (mrt_device.hpp),
 //                      in object order, so the accepted hits, their t and the
 //                      winner are those of the reference loop.
-//   full_trace_kernel  MRT_FLAG_FULL_TEST: the reference's determinants for
-//                      every pair, divisions deferred.
+//   full_trace_kernel  MRT_FLAG_FULL_TEST: a general-ray 3x3 solve (fused) for
+//                      every pair, the reference arithmetic for the survivors.
 //   cull_trace_kernel  MRT_FLAG_SCREEN_CULL (opt-in): lanes first test 64
 //                      primitives each against the whole wave tile.
 #include "mrt.h"
@@ -707,36 +707,48 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
 }
 
 // ---------------------------------------------------------------------------
-// MRT_FLAG_FULL_TEST: the reference's determinants for EVERY (pixel, primitive)
+// MRT_FLAG_FULL_TEST: a general-ray 3x3 solve for EVERY (pixel, primitive)
 // pair -- no screen-space rejection of any kind.
 //
 // tri_intersect (kernel.cl:197-235) solves by Cramer's rule: four 3x3
 // determinants det, Nb, Ng, Nt, then beta = Nb/det, gamma = Ng/det, t = Nt/det
-// and the range tests.  This kernel evaluates the four determinants for every
-// pair with the reference's own operation order (so they are the reference's
-// values bit for bit; the 2x2 minors det and Nb share are computed once, and
-// for the pinhole camera Nt does not depend on the pixel and comes with the
-// record) and postpones only the three divisions.  A hit needs t = Nt/det > 0,
-// so the sign s of det at a hit is known per triangle (the sign of Nt for the
-// pinhole camera, of det itself for the orthographic one) and a pair is dropped
-// when signs and magnitudes of the numerators already decide a range test:
-//     s Nb < 0 or s Ng < 0               beta < 0 or gamma < 0
-//     s (Nb + Ng) > s det (1 + 1e-5)     beta > 1 - gamma (covers gamma > 1)
-//     s Nt > s det bound (1 + 1e-5)      t above the closest hit so far, or t < 0
-// each with enough slack that the correctly rounded quotient fails the same
-// test, and with a band of 2^-100 max|det| around zero so that a quotient that
-// would round to -0 (which the reference's "< 0" lets through) is never
-// dropped.  Everything else takes the divisions through tri_exact.  Spheres:
-// the discriminant of circle_intersect (kernel.cl:248-254) for every pair; sqrt
-// and division only where it is not negative.
+// and the range tests.  With c = s2 x d and k = sol x d (s1 = a - b, s2 = a - c,
+// sol = a - origin, d the ray direction):
+//     det = s1 . c      Nb = sol . c      Ng = s1 . k      Nt = s1 . (s2 x sol)
+// This kernel evaluates, for every pair, both cross products and the three dot
+// products Nb, A = det - Nb = (s1 - sol) . c and Ng with fused multiply-adds
+// (mul + fma per cross component, three fma per dot product: 21 operations),
+// then W = A - Ng = det - Nb - Ng.  A hit needs Nb/det >= 0, Ng/det >= 0,
+// (Nb + Ng)/det <= 1 and t = Nt/det > 0; the sign s that det has at a hit is a
+// property of the triangle (the sign of Nt for the pinhole camera, where Nt does
+// not depend on the pixel; of det itself for the orthographic one), so a pair
+// whose s Nb, s Ng or s W is negative cannot be accepted.
+//
+// The fused values differ from the reference's unfused ones by rounding.  Both
+// are within 5 ulp-units of the sum of the absolute values of their six
+// products (P below) of the real-number determinant, so they differ by at
+// most 10 u P, u = 2^-24.  prep_full_records bounds P per triangle over all
+// pixels, takes 32 u P as the margin, adds the band that keeps a quotient
+// which would round to -0 (the reference's "< 0" lets it through) and an
+// absolute term for products in the denormal range, and the margin enters the
+// kernel as the starting value of each fma chain -- at no cost per pair.  So
+// the verdict "min(Nb, Ng, W) < 0" (for s = +1; "max > 0" for s = -1) is only
+// ever true for pairs the reference arithmetic rejects; every other pair (about
+// 0.05 % on the benchmark frames) runs tri_exact from the original vertices,
+// which decides, in registers, against the closest hit so far.  Triangles
+// whose margins cannot be bounded (overflowing or non-finite products) get a
+// record every pixel passes.  Spheres: the discriminant of circle_intersect
+// (kernel.cl:248-254) for every pair; sqrt and division only where it is not
+// negative.
 //
 // A lane owns 4x2 pixels, a wave 32x16, a block 64x32; the closest hit stays
-// in registers.  Records (3 x float4 per triangle, made by prep_full_records)
-// are staged through LDS in the same 12 KiB chunks as the prefilter records.
+// in registers.  Records (4 x float4 per triangle, made by prep_full_records)
+// are staged through LDS in chunks of 256 triangles (16 KiB).
 // ---------------------------------------------------------------------------
 constexpr int kFullPxX = 4, kFullPxY = 2, kFullSlots = kFullPxX * kFullPxY;
 constexpr int kFullWaveH = 8 * kFullPxY;          // 16 rows per wave
 constexpr int kFullBlockH = 2 * kFullWaveH;       // 32 rows per block
+constexpr int kFullChunkFloat4 = kChunkTris * kFullRecFloat4;
 
 namespace {
 
@@ -758,27 +770,39 @@ __device__ __forceinline__ float expand(F3 a, M3 m) {
     return det;
 }
 
-// One pair's verdict from its four determinants, for a triangle whose valid hits
-// have det > 0 (POS) or det < 0 (!POS).  POS: the smallest of Nb, Ng,
-// det (1 + 1e-5) - (Nb + Ng) and det bound (1 + 1e-5) - Nt; if it is below
-// -band, one of beta >= 0, gamma >= 0, beta <= 1 - gamma, t <= bound certainly
-// fails for the correctly rounded quotients (or det has the sign that makes t
-// negative).  !POS mirrors it: the largest of the four, above +band.  NaNs drop
-// out of v_min3 / v_max3; a pair whose determinants are not finite can never be
-// accepted (t is NaN, 0 or infinite), so any verdict is safe for it.
-template <bool POS>
-__device__ __forceinline__ float tri_verdict(float det, float nb, float ng, float nt, float bound_up, float rel_up) {
-    const float q2 = __builtin_fmaf(det, rel_up, -(nb + ng));
-    const float q3 = __builtin_fmaf(bound_up, det, -nt);
-    if (POS) return __builtin_fminf(__builtin_fminf(__builtin_fminf(nb, ng), q2), q3);
-    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nb, ng), q2), q3);
+// a x b with one rounded product and one fused multiply-add per component.
+__device__ __forceinline__ F3 cross_fused(F3 a, F3 b) {
+    return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)),
+               __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+               __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+// a . b + start as a chain of three fused multiply-adds.
+__device__ __forceinline__ float dot_fused(F3 a, F3 b, float start) {
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, __builtin_fmaf(a.x, b.x, start)));
+}
+
+// Sum of the absolute values of the six products of det3(a, b, c), for vectors of magnitudes.
+__device__ __forceinline__ double permabs(double ax, double ay, double az, double bx, double by, double bz,
+                                          double cx, double cy, double cz) {
+    return ax * (by * cz + bz * cy) + ay * (bx * cz + bz * cx) + az * (bx * cy + by * cx);
+}
+// x as a float that is not below it.
+__device__ __forceinline__ float float_up(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + 1u);     // x > 0 here: next float up
+    return f;
 }
 
 }  // namespace
 
-// Per-view triangle records of full_trace_kernel, by the same arithmetic as
-// tri_intersect: pinhole (s1 | s2 | a - eye | Nt, zero band), orthographic
-// (s1 | s2 | a | minors(s2, d)) with s1 = a - b, s2 = a - c (kernel.cl:204-206).
+// Per-view triangle records of full_trace_kernel, four float4 each.
+//   pinhole:       (s2 | Mb) (sol | Ma) (s1 - sol | Mg) (s1 | -)     sol = a - eye
+//   orthographic:  (s2 x d | Mb) (a | D + Ma) (s1 | Mg) (s1 x s2 | Mt)   d = -w, D = det
+// with s1 = a - b, s2 = a - c (kernel.cl:204-206) and M* the signed margins
+// described above (sign s of the group).  The kernel forms, per pixel,
+//   pinhole:       Nb = sol . (s2 x d) + Mb, A = (s1 - sol) . (s2 x d) + Ma, Ng = s1 . (sol x d) + Mg, W = A - Ng
+//   orthographic:  sol = a - origin, Nb = sol . (s2 x d) + Mb, Ng = s1 . (sol x d) + Mg,
+//                  W = (D + Ma) - Nb - Ng, Nt = sol . (s1 x s2) + Mt
 //
 // A hit needs t = Nt/det > 0, so the sign det has at a hit is a property of the
 // triangle: the sign of Nt for the pinhole camera (Nt does not depend on the
@@ -801,33 +825,84 @@ __global__ void prep_full_records(const RenderParams p, float4* __restrict__ rec
     const F3 a = mk3(va.x, va.y, va.z);
     const F3 s1 = sub3(a, mk3(vb.x, vb.y, vb.z));
     const F3 s2 = sub3(a, mk3(vc.x, vc.y, vc.z));
-    float4 r0, r1, r2;
+    const double u32 = 32.0 / 16777216.0;          // 32 u: the rounding budget per determinant
+    const double dx = p.ray_abs[0], dy = p.ray_abs[1], dz = p.ray_abs[2];
+    const double a1x = fabs((double)s1.x), a1y = fabs((double)s1.y), a1z = fabs((double)s1.z);
+    const double a2x = fabs((double)s2.x), a2y = fabs((double)s2.y), a2z = fabs((double)s2.z);
+    float4 r0, r1, r2, r3;
     float sign_src;
+    double p_all, mb, ma, mg, mt = 0.0;
     if (PROJ == MRT_PROJ_PERSP) {
         const F3 sol = sub3(a, mk3(p.eye[0], p.eye[1], p.eye[2]));
-        const float nt = det3(s1, s2, sol);
-        // |det| <= 6 max|s1| max|s2| max|d| for every pixel; 2^-100 of that is the zero band
-        const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(s1.x), __builtin_fabsf(s1.y)), __builtin_fabsf(s1.z));
-        const float m2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(s2.x), __builtin_fabsf(s2.y)), __builtin_fabsf(s2.z));
-        const float band = 6.1f * m1 * m2 * p.ray_absmax * 0x1p-100f;
-        r0 = make_float4(s1.x, s1.y, s1.z, s2.x);
-        r1 = make_float4(s2.y, s2.z, sol.x, sol.y);
-        r2 = make_float4(sol.z, nt, band == band ? band : __builtin_inff(), 0.0f);
-        sign_src = nt;
+        const F3 e = sub3(s1, sol);
+        sign_src = det3(s1, s2, sol);              // Nt, the reference's own value
+        const double sx = fabs((double)sol.x), sy = fabs((double)sol.y), sz = fabs((double)sol.z);
+        const double p_det = permabs(a1x, a1y, a1z, a2x, a2y, a2z, dx, dy, dz);
+        const double p_b = permabs(sx, sy, sz, a2x, a2y, a2z, dx, dy, dz);
+        const double p_g = permabs(a1x, a1y, a1z, sx, sy, sz, dx, dy, dz);
+        const double big = fmax(fmax(fmax(a1x, a1y), fmax(a1z, a2x)), fmax(fmax(a2y, a2z), fmax(fmax(sx, sy), fmax(sz, fmax(dx, fmax(dy, dz))))));
+        // |quotient| < 2^-149 rounds to -0, which passes "< 0"; products in the denormal range are
+        // off by 2^-150 absolutely, scaled by the factor they meet next
+        const double band = p_det * 0x1p-100 + 64.0 * 0x1p-149 * (1.0 + big);
+        p_all = p_det + p_b + p_g;
+        mb = u32 * p_b + band;
+        mg = u32 * p_g + band;
+        ma = mg + u32 * p_all + band;              // W = A - Ng carries Ng's margin with the other sign
+        r0 = make_float4(s2.x, s2.y, s2.z, 0.f);
+        r1 = make_float4(sol.x, sol.y, sol.z, 0.f);
+        r2 = make_float4(e.x, e.y, e.z, 0.f);
+        r3 = make_float4(s1.x, s1.y, s1.z, 0.f);
     } else {
-        const M3 m = minors(s2, mk3(-p.w[0], -p.w[1], -p.w[2]));
-        r0 = make_float4(s1.x, s1.y, s1.z, s2.x);
-        r1 = make_float4(s2.y, s2.z, a.x, a.y);
-        r2 = make_float4(a.z, m.m0, m.m1, m.m2);
-        sign_src = expand(s1, m);        // det, as the kernel computes it
+        const F3 d = mk3(-p.w[0], -p.w[1], -p.w[2]);
+        const F3 c = cross_fused(s2, d);
+        const F3 n = cross_fused(s1, s2);
+        const float det = expand(s1, minors(s2, d));   // det3(s1, s2, d), the reference's own value
+        sign_src = det;
+        const double sx = fabs((double)a.x) + p.org_abs[0], sy = fabs((double)a.y) + p.org_abs[1],
+                     sz = fabs((double)a.z) + p.org_abs[2];
+        const double p_det = permabs(a1x, a1y, a1z, a2x, a2y, a2z, dx, dy, dz);
+        const double p_b = permabs(sx, sy, sz, a2x, a2y, a2z, dx, dy, dz);
+        const double p_g = permabs(a1x, a1y, a1z, sx, sy, sz, dx, dy, dz);
+        const double p_t = permabs(a1x, a1y, a1z, a2x, a2y, a2z, sx, sy, sz);
+        const double big = fmax(fmax(fmax(a1x, a1y), fmax(a1z, a2x)), fmax(fmax(a2y, a2z), fmax(fmax(sx, sy), fmax(sz, fmax(dx, fmax(dy, dz))))));
+        const double band = p_det * 0x1p-100 + 64.0 * 0x1p-149 * (1.0 + big);
+        p_all = p_det + p_b + p_g + p_t;
+        mb = u32 * p_b + band;
+        mg = u32 * p_g + band;
+        mt = u32 * p_t + band;
+        ma = mb + mg + u32 * p_all + band;         // W = D - Nb - Ng carries both margins with the other sign
+        r0 = make_float4(c.x, c.y, c.z, 0.f);
+        r1 = make_float4(a.x, a.y, a.z, det);
+        r2 = make_float4(s1.x, s1.y, s1.z, 0.f);
+        r3 = make_float4(n.x, n.y, n.z, 0.f);
     }
+    float sg;
     uint32_t slot;
-    if (sign_src > 0.0f) slot = atomicAdd(&counts[0], 1u);
-    else if (sign_src < 0.0f) slot = p.n_tri - 1u - atomicAdd(&counts[1], 1u);
+    if (sign_src > 0.0f) { sg = 1.0f; slot = atomicAdd(&counts[0], 1u); }
+    else if (sign_src < 0.0f) { sg = -1.0f; slot = p.n_tri - 1u - atomicAdd(&counts[1], 1u); }
     else return;
-    rec[(size_t)slot * 3 + 0] = r0;
-    rec[(size_t)slot * 3 + 1] = r1;
-    rec[(size_t)slot * 3 + 2] = r2;
+    if (p_all < 1e36 && ma < 1e36) {               // false for NaN too
+        r0.w = sg * float_up(mb);
+        r2.w = sg * float_up(mg);
+        if (PROJ == MRT_PROJ_PERSP) {
+            r1.w = sg * float_up(ma);
+        } else {
+            // D + s Ma has the sign s; rounded away from zero
+            r1.w = sg * float_up(fabs((double)r1.w) + ma);
+            r3.w = sg * float_up(mt);
+        }
+    } else {
+        // The margins cannot be bounded: a record every pixel passes (all products zero, so
+        // Nb = Ng = s, W = 3 s or 2 s, Nt = s); the exact arithmetic decides every pair.
+        r0 = make_float4(0.f, 0.f, 0.f, sg);
+        r1 = make_float4(0.f, 0.f, 0.f, 4.0f * sg);
+        r2 = make_float4(0.f, 0.f, 0.f, sg);
+        r3 = make_float4(0.f, 0.f, 0.f, sg);
+    }
+    rec[(size_t)slot * kFullRecFloat4 + 0] = r0;
+    rec[(size_t)slot * kFullRecFloat4 + 1] = r1;
+    rec[(size_t)slot * kFullRecFloat4 + 2] = r2;
+    rec[(size_t)slot * kFullRecFloat4 + 3] = r3;
     ids[slot] = k;
 }
 
@@ -838,9 +913,10 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                                                                   const uint32_t* __restrict__ class_counts,
                                                                   float* __restrict__ t_out,
                                                                   int32_t* __restrict__ id_out, uint32_t pitch) {
-    __shared__ float4 s_rec[kChunkFloat4];
+    __shared__ float4 s_rec[kFullChunkFloat4];
     __shared__ uint32_t s_ids[kChunkTris];
     static_assert(kChunkTris == kBlockThreads, "one triangle id per thread when a chunk is staged");
+    static_assert(kChunkFloat4 <= kFullChunkFloat4, "the sphere chunks reuse the record buffer");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -854,7 +930,7 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
     // Per pixel: the part of the primary ray that depends on it (direction for the
     // pinhole camera, origin for the orthographic one) and the closest hit so far.
     F3 ray[kFullSlots];
-    float best_t[kFullSlots], bound_up[kFullSlots];
+    float best_t[kFullSlots];
     int32_t best_id[kFullSlots];
     F3 shared_part = mk3(0.f, 0.f, 0.f);   // the other half of the ray, the same for every pixel
     {
@@ -872,14 +948,12 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                 ray[j * kFullPxX + i] = (PROJ == MRT_PROJ_PERSP) ? d : o;
                 shared_part = (PROJ == MRT_PROJ_PERSP) ? o : d;
                 best_t[j * kFullPxX + i] = FLT_MAX;               // gfxraytrace.hpp:813
-                bound_up[j * kFullPxX + i] = __builtin_inff();
                 best_id[j * kFullPxX + i] = -1;
             }
         }
     }
 
     shared_part = mk3(in_vgpr(shared_part.x), in_vgpr(shared_part.y), in_vgpr(shared_part.z));
-    const float rel_up = in_vgpr(1.00001f);
 
     // ---- spheres: object ids 0 .. n_sph-1 ----
     for (uint32_t base = 0; base < p.n_sph; base += kChunkFloat4) {
@@ -916,7 +990,6 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                     bool two;
                     if (sphere_exact(center, sp.w, o, d, best_t[s], 0.0f, t, two) && t > 0.0f && t < best_t[s]) {
                         best_t[s] = t;
-                        bound_up[s] = t * 1.00001f;
                         best_id[s] = (int32_t)(base + g);
                     }
                 }
@@ -929,48 +1002,51 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
         constexpr bool POS = decltype(pos_tag)::value;
         for (uint32_t base = 0; base < n; base += kChunkTris) {
             __syncthreads();
-            stage_chunk(s_rec, full_rec + (size_t)(first + base) * 3, tid);   // the buffer has a chunk of slack
+            // the buffer has a chunk of slack beyond the last record
+#pragma unroll
+            for (int k = 0; k < kFullChunkFloat4 / kBlockThreads; ++k)
+                s_rec[tid + k * kBlockThreads] = full_rec[(size_t)(first + base) * kFullRecFloat4 + tid + k * kBlockThreads];
             s_ids[tid] = full_ids[first + base + tid];
             __syncthreads();
             if (!wave_active) continue;
             const uint32_t count = (n - base) < (uint32_t)kChunkTris ? (n - base) : (uint32_t)kChunkTris;
             for (uint32_t g = 0; g < count; ++g) {
-                const float4 q0 = s_rec[g * 3 + 0];
-                const float4 q1 = s_rec[g * 3 + 1];
-                const float4 q2 = s_rec[g * 3 + 2];
-                const F3 s1 = mk3(q0.x, q0.y, q0.z);
-                const F3 s2 = mk3(q0.w, q1.x, q1.y);
-                const F3 third = mk3(q1.z, q1.w, q2.x);     // a - eye (pinhole) or a (orthographic)
+                const float4 q0 = s_rec[g * kFullRecFloat4 + 0];
+                const float4 q1 = s_rec[g * kFullRecFloat4 + 1];
+                const float4 q2 = s_rec[g * kFullRecFloat4 + 2];
+                const float4 q3 = s_rec[g * kFullRecFloat4 + 3];
                 float acc = POS ? -__builtin_inff() : __builtin_inff();
-                float band;
                 if (PROJ == MRT_PROJ_PERSP) {
-                    const float nt = q2.y;
-                    band = q2.z;
+                    const F3 s2 = mk3(q0.x, q0.y, q0.z), sol = mk3(q1.x, q1.y, q1.z);
+                    const F3 e = mk3(q2.x, q2.y, q2.z), s1 = mk3(q3.x, q3.y, q3.z);
 #pragma unroll
                     for (int s = 0; s < kFullSlots; ++s) {
-                        const M3 m = minors(s2, ray[s]);
-                        const float det = expand(s1, m);
-                        const float nb = expand(third, m);
-                        const float ng = expand(s1, minors(third, ray[s]));
-                        const float v = tri_verdict<POS>(det, nb, ng, nt, bound_up[s], rel_up);
-                        acc = POS ? __builtin_fmaxf(acc, v) : __builtin_fminf(acc, v);
+                        const F3 c = cross_fused(s2, ray[s]);
+                        const F3 kk = cross_fused(sol, ray[s]);
+                        const float nb = dot_fused(sol, c, q0.w);
+                        const float aa = dot_fused(e, c, q1.w);
+                        const float ng = dot_fused(s1, kk, q2.w);
+                        const float w = aa - ng;
+                        if (POS) acc = __builtin_fmaxf(acc, __builtin_fminf(__builtin_fminf(nb, ng), w));
+                        else acc = __builtin_fminf(acc, __builtin_fmaxf(__builtin_fmaxf(nb, ng), w));
                     }
                 } else {
-                    M3 m;
-                    m.m0 = q2.y; m.m1 = q2.z; m.m2 = q2.w;
-                    const float det = expand(s1, m);
-                    band = __builtin_fabsf(det) * 0x1p-100f;
+                    const F3 c = mk3(q0.x, q0.y, q0.z), a = mk3(q1.x, q1.y, q1.z);
+                    const F3 s1 = mk3(q2.x, q2.y, q2.z), nrm = mk3(q3.x, q3.y, q3.z);
 #pragma unroll
                     for (int s = 0; s < kFullSlots; ++s) {
-                        const F3 sol = sub3(third, ray[s]);
-                        const float nb = expand(sol, m);
-                        const float ng = expand(s1, minors(sol, shared_part));
-                        const float nt = expand(s1, minors(s2, sol));
-                        const float v = tri_verdict<POS>(det, nb, ng, nt, bound_up[s], rel_up);
-                        acc = POS ? __builtin_fmaxf(acc, v) : __builtin_fminf(acc, v);
+                        const F3 sol = sub3(a, ray[s]);                   // as tri_intersect forms it
+                        const F3 kk = cross_fused(sol, shared_part);
+                        const float nb = dot_fused(sol, c, q0.w);
+                        const float ng = dot_fused(s1, kk, q2.w);
+                        const float nt = dot_fused(sol, nrm, q3.w);
+                        const float w = (q1.w - nb) - ng;
+                        if (POS) acc = __builtin_fmaxf(acc, __builtin_fminf(__builtin_fminf(__builtin_fminf(nb, ng), w), nt));
+                        else acc = __builtin_fminf(acc, __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nb, ng), w), nt));
                     }
                 }
-                const bool cand = POS ? (acc >= -band) : (acc <= band);
+                // not "acc < 0": an acc that is NaN (non-finite rays) may go either way, no such pair is a hit
+                const bool cand = POS ? (acc >= 0.0f) : (acc <= 0.0f);
                 if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
                 if (cand) {
                     const uint32_t ti = __builtin_amdgcn_readfirstlane(s_ids[g]);
@@ -989,7 +1065,6 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                         if (tri_exact(A, B, C, o, d, best_t[s], 0.0f, t) && t > 0.0f &&
                             (t < best_t[s] || (t == best_t[s] && obj_id < best_id[s]))) {
                             best_t[s] = t;
-                            bound_up[s] = t * 1.00001f;
                             best_id[s] = obj_id;
                         }
                     }

@@ -25,6 +25,7 @@ constexpr int kBlockTileY = kWaveTile * kBlockWavesY;             // 64
 // one.  kGroup* primitives are tested between two "does any lane pass?" votes.
 constexpr int kChunkTris = 256;
 constexpr int kChunkFloat4 = kChunkTris * 3;
+constexpr int kFullRecFloat4 = 4;          // float4 per triangle record of full_trace_kernel
 #ifndef MRT_GROUP_TRIS
 #define MRT_GROUP_TRIS 4
 #endif
@@ -47,7 +48,8 @@ struct RenderParams {
     float left, right, top, bottom;
     float xres_f, yres_f;
     float focal;
-    float ray_absmax;               // upper bound of |component| of any primary-ray direction
+    float ray_abs[3];               // per component: upper bound of |direction| over all primary rays
+    float org_abs[3];               // per component: upper bound of |origin| over all primary rays
     float ka, kd, ks;
     float amb[3];
     float bg[3];
