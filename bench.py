@@ -238,6 +238,27 @@ def secondary_workloads(env, mkscene):
     return res
 
 
+def set_camera_cost(env, sc, reps=50):
+    """mrt_set_camera (per-view records rebuilt on the GPU, asynchronous): milliseconds the call
+    keeps the host, and milliseconds per view including the device work, back to back."""
+    import torch
+    ctx = env.mrt.Context(device=env.dev_index)
+    try:
+        ctx.set_scene(sc)
+        ctx.set_camera(sc)
+        torch.cuda.synchronize(env.dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.set_camera(sc)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize(env.dev)
+        t2 = time.perf_counter()
+    finally:
+        ctx.close()
+    return {"host_call_ms": (t1 - t0) / reps * 1e3, "with_device_work_ms": (t2 - t0) / reps * 1e3,
+            "primitives": sc.struct.n_spheres + sc.struct.n_tris}
+
+
 def host_frame(env, job, total_rays):
     """What the CLI pays on top of the kernels: D2H into page-locked host memory (mrt_host_alloc,
     as the CLI does) and into ordinary pageable memory, then the PNG encode."""
@@ -380,6 +401,11 @@ def main():
         }
         if host is not None:
             out["host_frame"] = host
+            cam_t = set_camera_cost(env, sc)
+            cam_s = set_camera_cost(env, mrt.LoadedScene(text=mkscene.soup(1024, 1024)).copy())
+            out["set_camera_ms_teatime"] = cam_t["with_device_work_ms"]
+            out["set_camera_ms_soup"] = cam_s["with_device_work_ms"]
+            out["set_camera"] = {"teatime_4k": cam_t, "soup_17408_primitives": cam_s}
     if not args.no_secondary:
         sec = secondary_workloads(env, mkscene)
         if rank == 0:

@@ -4,7 +4,9 @@
 // context, compiled kernel.cl, allocated buffers, copied in, launched with a
 // fixed 160000 work-items and copied out (CLHelpers.hpp:76-322), a context
 // here owns one stream and its device buffers for its whole life, the scene is
-// uploaded once (mrt_set_scene) and a frame is one kernel launch.
+// uploaded once (mrt_set_scene), a change of view re-derives the per-view
+// records on the GPU (mrt_set_camera, no copies, no waiting) and a frame is one
+// or two kernel launches.
 #include "mrt.h"
 #include "mrt_kernels.hpp"
 
@@ -30,6 +32,10 @@ __global__ void full_trace_kernel(const RenderParams p, const float4* full_rec, 
                                   const uint32_t* class_counts, float* t_out, int32_t* id_out, uint32_t pitch);
 template <int PROJ>
 __global__ void prep_full_records(const RenderParams p, float4* rec, uint32_t* ids, uint32_t* counts);
+__global__ void build_triangle_records(const ViewDerived w, const float4* tri_exact, uint32_t n_tri,
+                                       uint32_t n_tri_padded, float4* tri_filter, float4* tri_circle);
+__global__ void build_sphere_records(const ViewDerived w, const float4* sph, uint32_t n_sph, uint32_t n_sph_padded,
+                                     float4* sph_filter);
 template <int PROJ>
 __global__ void shade_kernel(const RenderParams p, const float* t_in, const int32_t* id_in, uint32_t pitch);
 template <int PROJ>
@@ -81,10 +87,11 @@ struct mrt_ctx {
     int projection = 0;
     double upload_ms = 0.0;
 
-    // Host copy of the geometry planes (the per-view prefilter records are rebuilt
-    // from them when only the camera changes) and the scene header they belong to.
-    std::vector<float> h_tri[9], h_sph[4];
+    // The scene header (camera, viewport, counts; no plane pointers): the per-view records are
+    // rebuilt on the GPU from the geometry already there when only the camera changes.
     mrt_scene h_scene{};
+    hipEvent_t records_ready = nullptr;      // behind the last record build on ctx->stream
+    bool records_pending = false;
 
     // scene buffers
     void* d_sph_filter = nullptr;
@@ -169,343 +176,6 @@ int upload(mrt_ctx* ctx, void*& dst, const std::vector<T>& src) {
     if (!src.empty())
         HIP_TRY(ctx, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return MRT_OK;
-}
-
-// As upload(), but keeps the allocation when the size has not changed.
-template <typename T>
-int upload_reuse(mrt_ctx* ctx, void*& dst, size_t& cap_bytes, const std::vector<T>& src) {
-    const size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
-    if (!dst || cap_bytes != bytes) {
-        free_dev(dst);
-        cap_bytes = 0;
-        HIP_TRY(ctx, hipMalloc(&dst, bytes));
-        cap_bytes = bytes;
-    }
-    if (!src.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    return MRT_OK;
-}
-
-// ---------------------------------------------------------------------------
-// Per-frame triangle prefilter records.
-//
-// For a pinhole camera the ray direction is affine in the pixel (px, py) and
-// the origin is fixed; for the orthographic camera it is the other way round
-// (kernel.cl:130-147 with the pixel grid of gfxraytrace.hpp:850-852).  The
-// three numerators Cramer's rule divides by the common determinant
-// (kernel.cl:187-195, :208-213) are therefore affine functions of (px, py).
-// With s the sign that makes a valid hit (t > 0) have a positive determinant,
-// a pixel can only hit if  E0 = s*U >= 0, E1 = s*V >= 0, E2 = s*(Det-U-V) >= 0
-// -- up to the rounding error of the FP32 evaluation the exact path performs.
-// That error is bounded here term by term and added to each edge's constant,
-// so the filter passes every pair the exact arithmetic can accept.  Triangles
-// whose sign cannot be decided (eye in the triangle's plane, ray parallel to
-// it) get a record that always passes.
-// ---------------------------------------------------------------------------
-struct D3 { double x, y, z; };
-inline D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-inline D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-inline D3 operator*(D3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-inline double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-inline D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-inline D3 absv(D3 a) { return {std::fabs(a.x), std::fabs(a.y), std::fabs(a.z)}; }
-// Sum of the absolute values of the six products of a 3x3 determinant.
-inline double permabs(D3 a, D3 b, D3 c) {
-    return a.x * (b.y * c.z + b.z * c.y) + a.y * (b.x * c.z + b.z * c.x) + a.z * (b.x * c.y + b.y * c.x);
-}
-
-const float kAlways = 1e30f;
-
-// The relative rounding budget K assumes normal numbers.  A product that lands in the denormal
-// range is off by up to 2^-150 absolutely instead, and the factor it is multiplied by next
-// scales that; 64 such errors times the largest factor in play is far more than a determinant
-// of these four vectors can collect.
-inline double tiny_abs(D3 a, D3 b, D3 c, D3 d) {
-    auto m = [](D3 v) { return std::fmax(std::fabs(v.x), std::fmax(std::fabs(v.y), std::fabs(v.z))); };
-    return 64.0 * 0x1p-149 * (1.0 + std::fmax(std::fmax(m(a), m(b)), std::fmax(m(c), m(d))));
-}
-
-// One edge function A*x + B*y + C of a triangle record.
-struct Edge { float A, B, C; };
-
-// Triangle record as the kernel reads it from LDS: two 16-byte loads and one
-// 4-byte load, (A0,B0,C0,A1) (B1,C1,A2,B2) (C2,-,-,-).
-// The last three floats are the block-origin constants of the opt-in 4x4 block
-// reject: C'_k = C_k + 3*max(A_k,0) + 3*max(B_k,0), rounded up.
-void push_record(std::vector<float4>& rec, const Edge e[3]) {
-    float cb[3];
-    for (int k = 0; k < 3; ++k) {
-        const double span = 3.0 * std::fmax((double)e[k].A, 0.0) + 3.0 * std::fmax((double)e[k].B, 0.0);
-        double c = (double)e[k].C + span;
-        c += 4.0 / 16777216.0 * (std::fabs(c) + span) + 1e-30;
-        cb[k] = (float)c;
-        if ((double)cb[k] < c) cb[k] = std::nextafterf(cb[k], INFINITY);
-        if (!(std::fabs(cb[k]) < 1e30f)) cb[k] = cb[k] > 0 ? 1e30f : -1e30f;
-    }
-    rec.push_back(make_float4(e[0].A, e[0].B, e[0].C, e[1].A));
-    rec.push_back(make_float4(e[1].B, e[1].C, e[2].A, e[2].B));
-    rec.push_back(make_float4(e[2].C, cb[0], cb[1], cb[2]));
-}
-
-void push_const_record(std::vector<float4>& rec, float c) {
-    const Edge e[3] = {{0.f, 0.f, c}, {0.f, 0.f, c}, {0.f, 0.f, c}};
-    push_record(rec, e);
-}
-
-Edge make_edge(double a, double b, double c, double margin, double xres, double yres) {
-    double g = std::hypot(a, b);
-    double A, B, C;
-    if (g > 0.0 && std::isfinite(g)) {
-        // Unit gradient: the value is a signed distance in pixels.
-        A = a / g; B = b / g; C = (c + margin) / g + 0.0625;
-    } else if (std::isfinite(c)) {
-        A = 0; B = 0; C = (c + margin >= 0.0) ? 1.0 : -1.0;
-    } else {
-        A = 0; B = 0; C = 1.0;
-    }
-    // Rounding of the three coefficients to float and of the two fused
-    // multiply-adds (plus up to three additions along a row) in the kernel.
-    C += 16.0 * (1.0 / 16777216.0) * (std::fabs(A) * xres + std::fabs(B) * yres + std::fabs(C));
-    if (!(std::fabs(C) < 1e30)) C = (C > 0 || C != C) ? 1e30 : -1e30;
-    return Edge{(float)A, (float)B, (float)C};
-}
-
-void build_filter_records(const mrt_scene& s, std::vector<float4>& rec) {
-    const double K = 32.0 / 16777216.0;   // 32 ulp(1)/2: generous per-term rounding budget
-    const double xres = s.xres, yres = s.yres;
-    // uv(px) = u0 + u1*px for 0-based pixel index px (kernel.cl:126-127 with
-    // pos = px + 1); (right-left) is a float subtraction in the reference.
-    const double ux1 = (double)(float)(s.right - s.left) / (double)(float)s.xres;
-    const double uy1 = (double)(float)(s.top - s.bottom) / (double)(float)s.yres;
-    const double ux0 = (double)s.left + 1.5 * ux1;
-    const double uy0 = (double)s.bottom + 1.5 * uy1;
-    const double mux = std::fmax(std::fabs(ux0), std::fabs(ux0 + ux1 * (xres - 1)));
-    const double muy = std::fmax(std::fabs(uy0), std::fabs(uy0 + uy1 * (yres - 1)));
-    const D3 eye{s.eye[0], s.eye[1], s.eye[2]}, cu{s.u[0], s.u[1], s.u[2]}, cv{s.v[0], s.v[1], s.v[2]},
-        cw{s.w[0], s.w[1], s.w[2]};
-    const bool persp = s.projection == MRT_PROJ_PERSP;
-    const double f = s.focal;
-    // Affine pixel dependence: persp direction / ortho origin = V0 + Vx*px + Vy*py.
-    const D3 Vx = cu * ux1, Vy = cv * uy1;
-    const D3 V0 = persp ? (cw * (-f) + cu * ux0 + cv * uy0) : (cu * ux0 + cv * uy0);
-    const D3 vabs = persp ? (absv(cw) * f + absv(cu) * mux + absv(cv) * muy) : (absv(cu) * mux + absv(cv) * muy);
-    const D3 dortho = cw * (-1.0);
-
-    rec.clear();
-    rec.reserve(((size_t)s.n_tris + mrt::kChunkTris) * 3);
-    for (uint32_t k = 0; k < s.n_tris; ++k) {
-        const D3 a{s.tri[0][k], s.tri[1][k], s.tri[2][k]};
-        const D3 b{s.tri[3][k], s.tri[4][k], s.tri[5][k]};
-        const D3 c{s.tri[6][k], s.tri[7][k], s.tri[8][k]};
-        const D3 s1 = a - b, s2 = a - c;
-        const D3 n = cross(s1, s2);
-        if (persp) {
-            const D3 sol = a - eye;
-            const double T = dot(sol, n);
-            const double dT = K * permabs(absv(s1), absv(s2), absv(sol));
-            if (!(std::fabs(T) > dT)) { push_const_record(rec, kAlways); continue; }
-            const double sg = T > 0 ? 1.0 : -1.0;
-            const D3 P0 = cross(sol, s2), P1 = cross(s1, sol);
-            const D3 P2 = n - P0 - P1;
-            const double dD = K * permabs(absv(s1), absv(s2), vabs);
-            const double maxD = dot(absv(n), vabs);
-            // A quotient below half the smallest denormal rounds to -0, which the reference's
-            // "beta < 0" lets through: a numerator within 2^-148 |det| of zero must pass too.
-            const double zero_band = maxD * 0x1p-148 + tiny_abs(s1, s2, sol, vabs);
-            const double dU = K * permabs(absv(sol), absv(s2), vabs) + zero_band;
-            const double dV = K * permabs(absv(s1), absv(sol), vabs) + zero_band;
-            const double m2 = dU + dV + 2 * dD + K * maxD + zero_band;
-            const Edge e[3] = {
-                make_edge(sg * dot(P0, Vx), sg * dot(P0, Vy), sg * dot(P0, V0), dU, xres, yres),
-                make_edge(sg * dot(P1, Vx), sg * dot(P1, Vy), sg * dot(P1, V0), dV, xres, yres),
-                make_edge(sg * dot(P2, Vx), sg * dot(P2, Vy), sg * dot(P2, V0), m2, xres, yres)};
-            push_record(rec, e);
-        } else {
-            const D3 d = dortho;
-            const double Det = dot(d, n);
-            const double dD = K * permabs(absv(s1), absv(s2), absv(d));
-            if (!(std::fabs(Det) > dD)) { push_const_record(rec, kAlways); continue; }
-            const double sg = Det > 0 ? 1.0 : -1.0;
-            const D3 solabs = absv(a) + vabs;
-            const D3 Q0 = cross(s2, d), Q1 = cross(d, s1);
-            const D3 a0 = a - V0;   // sol = a0 - Vx*px - Vy*py
-            // as above: quotients that round to -0, products in the denormal range
-            const double zero_band = std::fabs(Det) * 0x1p-148 + tiny_abs(s1, s2, solabs, absv(d));
-            const double dU = K * permabs(solabs, absv(s2), absv(d)) + zero_band;
-            const double dV = K * permabs(absv(s1), solabs, absv(d)) + zero_band;
-            const double m2 = dU + dV + 2 * dD + K * std::fabs(Det) + zero_band;
-            const double u0 = dot(a0, Q0), ux = -dot(Vx, Q0), uy = -dot(Vy, Q0);
-            const double v0 = dot(a0, Q1), vx = -dot(Vx, Q1), vy = -dot(Vy, Q1);
-            const Edge e[3] = {
-                make_edge(sg * ux, sg * uy, sg * u0, dU, xres, yres),
-                make_edge(sg * vx, sg * vy, sg * v0, dV, xres, yres),
-                make_edge(sg * (-ux - vx), sg * (-uy - vy), sg * (Det - u0 - v0), m2, xres, yres)};
-            push_record(rec, e);
-        }
-    }
-    // Pad to whole chunks with records no pixel passes.
-    while ((rec.size() / 3) % mrt::kChunkTris != 0) push_const_record(rec, -kAlways);
-}
-
-// ---------------------------------------------------------------------------
-// Per-frame sphere prefilter records (sx, ox, sy, oy): a pixel (x, y) can only
-// hit the sphere if (x*sx + ox)^2 + (y*sy + oy)^2 <= 1.  The ellipse is the
-// one circumscribing the pixel-space bounding box of the sphere's outline
-// (tangent rays from the eye for the pinhole camera, centre +- r for the
-// orthographic one), grown by a margin that covers the cancellation error of
-// the FP32 discriminant b*b - a*c the exact path evaluates (kernel.cl:248-254).
-// A sphere whose outline is unbounded or cannot be bounded reliably (it
-// reaches the eye plane, or the camera basis is not orthonormal) gets a
-// record every pixel passes.
-// ---------------------------------------------------------------------------
-void build_sphere_records(const mrt_scene& s, std::vector<float4>& rec) {
-    const float4 always = make_float4(0.f, 0.f, 0.f, 0.f);   // 0 + 0 <= 1
-    const float4 never = make_float4(0.f, 2.f, 0.f, 0.f);    // 4 > 1
-    const double xres = s.xres, yres = s.yres;
-    const double ux1 = (double)(float)(s.right - s.left) / (double)(float)s.xres;
-    const double uy1 = (double)(float)(s.top - s.bottom) / (double)(float)s.yres;
-    const double ux0 = (double)s.left + 1.5 * ux1;
-    const double uy0 = (double)s.bottom + 1.5 * uy1;
-    const D3 eye{s.eye[0], s.eye[1], s.eye[2]}, cu{s.u[0], s.u[1], s.u[2]}, cv{s.v[0], s.v[1], s.v[2]},
-        cw{s.w[0], s.w[1], s.w[2]};
-    const bool persp = s.projection == MRT_PROJ_PERSP;
-    const double f = s.focal;
-    const double tol = 1e-4;
-    const bool orthonormal = std::fabs(dot(cu, cu) - 1) < tol && std::fabs(dot(cv, cv) - 1) < tol &&
-                             std::fabs(dot(cw, cw) - 1) < tol && std::fabs(dot(cu, cv)) < tol &&
-                             std::fabs(dot(cu, cw)) < tol && std::fabs(dot(cv, cw)) < tol;
-    const double mux = std::fmax(std::fabs(ux0), std::fabs(ux0 + ux1 * (xres - 1)));
-    const double muy = std::fmax(std::fabs(uy0), std::fabs(uy0 + uy1 * (yres - 1)));
-    const double K = 64.0 / 16777216.0;
-
-    rec.clear();
-    rec.reserve((size_t)s.n_spheres + mrt::kChunkFloat4);
-    for (uint32_t k = 0; k < s.n_spheres; ++k) {
-        const D3 c{s.sph[0][k], s.sph[1][k], s.sph[2][k]};
-        const double r = std::fabs((double)s.sph[3][k]);
-        float4 out = always;
-        if (orthonormal && r > 0 && std::isfinite(r) && ux1 > 0 && uy1 > 0) {
-            double lo_u, hi_u, lo_v, hi_v, margin;
-            bool ok = true;
-            if (persp) {
-                const D3 oc = c - eye;
-                const double X = dot(oc, cu), Y = dot(oc, cv), Z = -dot(oc, cw);
-                const double rr = r * 1.001;
-                ok = f > 0 && Z > rr * 1.001 + 1e-30;
-                if (ok) {
-                    const double den = Z * Z - rr * rr;
-                    const double sx = rr * std::sqrt(X * X + den), sy = rr * std::sqrt(Y * Y + den);
-                    lo_u = f * (X * Z - sx) / den; hi_u = f * (X * Z + sx) / den;
-                    lo_v = f * (Y * Z - sy) / den; hi_v = f * (Y * Z + sy) / den;
-                    const double dist = std::sqrt(dot(oc, oc));
-                    const double dmax2 = f * f + mux * mux + muy * muy;
-                    // b*b and a*c (kernel.cl:250-254) must stay clear of the denormal range, where the
-                    // relative error model of the margin does not hold
-                    if (f * f * r * r < 1e-30) ok = false;
-                    // error of b*b - a*c over its gradient at the outline, in pixels
-                    margin = 1.0 + K * dist * dmax2 / (r * std::fmin(ux1, uy1) * f);
-                }
-            } else {
-                const double U = dot(c, cu), V = dot(c, cv);
-                lo_u = U - r * 1.001; hi_u = U + r * 1.001;
-                lo_v = V - r * 1.001; hi_v = V + r * 1.001;
-                const double reach = std::sqrt(dot(c, c)) + mux + muy + r;
-                margin = 1.0 + K * reach * reach / (r * std::fmin(ux1, uy1));
-                if (r * r < 1e-30) ok = false;      // as for the pinhole camera
-            }
-            if (ok && std::isfinite(margin) && margin < 1e6) {
-                const double px0 = (lo_u - ux0) / ux1, px1 = (hi_u - ux0) / ux1;
-                const double py0 = (lo_v - uy0) / uy1, py1 = (hi_v - uy0) / uy1;
-                const double xc = 0.5 * (px0 + px1), yc = 0.5 * (py0 + py1);
-                const double hx = 0.5 * std::fabs(px1 - px0), hy = 0.5 * std::fabs(py1 - py0);
-                const double ax = 1.41421357 * hx + margin, ay = 1.41421357 * hy + margin;
-                if (std::isfinite(xc) && std::isfinite(yc) && std::isfinite(ax) && std::isfinite(ay)) {
-                    // grow once more for the FP32 evaluation of the two squares in the kernel
-                    const double grow = 1.0 + 1e-5 * (1.0 + (std::fabs(xc) + xres) / ax + (std::fabs(yc) + yres) / ay);
-                    const double sxx = 1.0 / (ax * grow), syy = 1.0 / (ay * grow);
-                    out = make_float4((float)sxx, (float)(-xc * sxx), (float)syy, (float)(-yc * syy));
-                    if (!std::isfinite(out.x) || !std::isfinite(out.y) || !std::isfinite(out.z) || !std::isfinite(out.w))
-                        out = always;
-                }
-            }
-        }
-        rec.push_back(out);
-    }
-    while (rec.size() % mrt::kChunkFloat4 != 0) rec.push_back(never);
-}
-
-// ---------------------------------------------------------------------------
-// Bounding circle of a triangle's prefilter region, (xc, yc, R^2, -).
-//
-// The region the three edge functions pass is the triangle whose sides are the
-// lines E_k = 0 of the record exactly as stored (floats, margins included).
-// Its corners are the pairwise intersections of those lines; the smallest
-// circle around them (diameter on the longest side when the third corner lies
-// inside, else the circumcircle), grown by a margin for the FP32 evaluation in
-// the kernel, therefore contains every pixel the edge test can pass.  Records
-// whose region is unbounded, degenerate or cannot be bounded reliably get a
-// circle every pixel passes; padding records get one no pixel passes.
-// ---------------------------------------------------------------------------
-void build_circle_records(const std::vector<float4>& rec, uint32_t n_tris, double xres, double yres,
-                          std::vector<float4>& circ) {
-    const float4 always = make_float4(0.f, 0.f, 1e30f, 0.f);
-    const float4 never = make_float4(0.f, 0.f, -1.0f, 0.f);
-    const size_t n_padded = rec.size() / 3;
-    circ.assign(n_padded, never);
-    for (size_t k = 0; k < n_tris; ++k) {
-        const float4 q0 = rec[3 * k], q1 = rec[3 * k + 1], q2 = rec[3 * k + 2];
-        const double A[3] = {q0.x, q0.w, q1.z}, B[3] = {q0.y, q1.x, q1.w}, C[3] = {q0.z, q1.y, q2.x};
-        circ[k] = always;
-        bool ok = true;
-        double px[3], py[3];
-        for (int e = 0; e < 3 && ok; ++e) {
-            const int i = e, j = (e + 1) % 3, o = (e + 2) % 3;
-            const double det = A[i] * B[j] - A[j] * B[i];
-            if (!(std::fabs(det) > 1e-9)) { ok = false; break; }
-            px[e] = (B[i] * C[j] - B[j] * C[i]) / det;
-            py[e] = (A[j] * C[i] - A[i] * C[j]) / det;
-            // the corner must satisfy the third inequality, or the region is not a bounded triangle
-            const double third = A[o] * px[e] + B[o] * py[e] + C[o];
-            if (!(third >= -1e-6 * (std::fabs(A[o] * px[e]) + std::fabs(B[o] * py[e]) + std::fabs(C[o]) + 1.0))) ok = false;
-            if (!std::isfinite(px[e]) || !std::isfinite(py[e])) ok = false;
-        }
-        if (!ok) continue;
-        // smallest enclosing circle of three points
-        double best_d2 = -1; int bi = 0, bj = 1;
-        for (int i = 0; i < 3; ++i) {
-            const int j = (i + 1) % 3;
-            const double d2 = (px[i] - px[j]) * (px[i] - px[j]) + (py[i] - py[j]) * (py[i] - py[j]);
-            if (d2 > best_d2) { best_d2 = d2; bi = i; bj = j; }
-        }
-        const int bk = 3 - bi - bj;
-        double cx = 0.5 * (px[bi] + px[bj]), cy = 0.5 * (py[bi] + py[bj]);
-        double r = 0.5 * std::sqrt(best_d2);
-        const double dk = std::hypot(px[bk] - cx, py[bk] - cy);
-        if (dk > r) {
-            // circumcircle
-            const double ax = px[0], ay = py[0], bx = px[1], by = py[1], cx2 = px[2], cy2 = py[2];
-            const double d = 2.0 * (ax * (by - cy2) + bx * (cy2 - ay) + cx2 * (ay - by));
-            if (std::fabs(d) > 1e-300) {
-                const double a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx2 * cx2 + cy2 * cy2;
-                cx = (a2 * (by - cy2) + b2 * (cy2 - ay) + c2 * (ay - by)) / d;
-                cy = (a2 * (cx2 - bx) + b2 * (ax - cx2) + c2 * (bx - ax)) / d;
-                r = 0.0;
-                for (int i = 0; i < 3; ++i) r = std::fmax(r, std::hypot(px[i] - cx, py[i] - cy));
-            } else {
-                cx = (px[0] + px[1] + px[2]) / 3.0; cy = (py[0] + py[1] + py[2]) / 3.0;
-                r = 0.0;
-                for (int i = 0; i < 3; ++i) r = std::fmax(r, std::hypot(px[i] - cx, py[i] - cy));
-            }
-        }
-        if (!std::isfinite(cx) || !std::isfinite(cy) || !std::isfinite(r)) continue;
-        // FP32 evaluation: x - xc and y - yc are rounded at the magnitude of the larger
-        // operand, then squared; cover that and the rounding of the record itself.
-        const double reach = std::fabs(cx) + std::fabs(cy) + xres + yres + r;
-        r += 0.5 + 32.0 / 16777216.0 * reach;
-        const double r2 = r * r * (1.0 + 1e-5);
-        if (!(r2 < 1e29) || std::fabs(cx) > 1e15 || std::fabs(cy) > 1e15) continue;
-        circ[k] = make_float4((float)cx, (float)cy, (float)r2, 0.f);
-    }
 }
 
 int check_scene(mrt_ctx* ctx, const mrt_scene* s) {
@@ -642,6 +312,9 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     // The planes are shared by all frames of this ctx: a frame on another stream waits for the last one.
     if (planes.own && ctx->frame_pending && stream != ctx->last_stream)
         HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->frame_done, 0));
+    // The per-view records are built on the ctx's own stream.
+    if (ctx->records_pending && stream != ctx->stream)
+        HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->records_ready, 0));
     if (p.exact_counter) HIP_TRY(ctx, hipMemsetAsync(p.exact_counter, 0, sizeof(unsigned long long), stream));
 
     const dim3 tgrid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY);
@@ -790,6 +463,7 @@ int mrt_create(const mrt_config* cfg, mrt_ctx** out) {
     for (int k = 0; k < 3; ++k)
         if ((e = hipEventCreate(&ctx->ev[k])) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->frame_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->records_ready, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&ctx->d_counter, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = scratch_address(dev, &ctx->scratch_keys)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     *out = ctx;
@@ -812,26 +486,54 @@ void mrt_destroy(mrt_ctx* ctx) {
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     for (int k = 0; k < 3; ++k) if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->frame_done) (void)hipEventDestroy(ctx->frame_done);
+    if (ctx->records_ready) (void)hipEventDestroy(ctx->records_ready);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
-// Derives the per-view prefilter records from ctx->h_scene, uploads them and
-// refreshes the camera part of the kernel parameters.
-static int rebuild_view(mrt_ctx* ctx) {
-    const mrt_scene* s = &ctx->h_scene;
-    std::vector<float4> filt, sfilt, circ;
-    build_filter_records(*s, filt);
-    build_sphere_records(*s, sfilt);
-    build_circle_records(filt, s->n_tris, s->xres, s->yres, circ);
-    int rc;
-    if ((rc = upload_reuse(ctx, ctx->d_sph_filter, ctx->cap_sph_filter, sfilt)) != MRT_OK) return rc;
-    if ((rc = upload_reuse(ctx, ctx->d_tri_filter, ctx->cap_tri_filter, filt)) != MRT_OK) return rc;
-    if ((rc = upload_reuse(ctx, ctx->d_tri_circle, ctx->cap_tri_circle, circ)) != MRT_OK) return rc;
-    // The staging vectors are pageable and die with this call.
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+// (Re)allocates a device buffer when its size changes.
+static int reserve(mrt_ctx* ctx, void*& dst, size_t& cap_bytes, size_t bytes) {
+    if (!dst || cap_bytes != bytes) {
+        free_dev(dst);
+        cap_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&dst, bytes));
+        cap_bytes = bytes;
+    }
+    return MRT_OK;
+}
 
+// Derives the per-view records from ctx->h_scene's header and the geometry already on the GPU
+// (kernels of mrt_records.hip on ctx->stream, nothing is copied and nothing waits) and refreshes
+// the camera part of the kernel parameters.  may_allocate: called from mrt_set_scene, where the
+// record buffers may change size; mrt_set_camera finds them as mrt_set_scene left them.
+static int rebuild_view(mrt_ctx* ctx, bool may_allocate) {
+    const mrt_scene* s = &ctx->h_scene;
     RenderParams& p = ctx->params;
+    const uint32_t n_tri_padded = round_up(s->n_tris ? s->n_tris : 1, mrt::kChunkTris);
+    const uint32_t n_sph_padded = round_up(s->n_spheres ? s->n_spheres : 1, mrt::kChunkFloat4);
+    // Records of full_trace_kernel: one chunk of slack, the kernel stages whole LDS chunks from
+    // wherever a sign group starts (it never tests what lies beyond the group).
+    const size_t n_full = (size_t)n_tri_padded + mrt::kChunkTris;
+    const size_t full_bytes = n_full * mrt::kFullRecFloat4 * sizeof(float4);
+    const bool full = (ctx->flags & MRT_FLAG_FULL_TEST) != 0;
+    if (may_allocate) {
+        int rc;
+        if ((rc = reserve(ctx, ctx->d_sph_filter, ctx->cap_sph_filter, (size_t)n_sph_padded * sizeof(float4))) != MRT_OK) return rc;
+        if ((rc = reserve(ctx, ctx->d_tri_filter, ctx->cap_tri_filter, (size_t)n_tri_padded * 3 * sizeof(float4))) != MRT_OK) return rc;
+        if ((rc = reserve(ctx, ctx->d_tri_circle, ctx->cap_tri_circle, (size_t)n_tri_padded * sizeof(float4))) != MRT_OK) return rc;
+        if (full) {
+            if (!ctx->d_full_rec || ctx->cap_full_rec != full_bytes) {
+                free_dev(ctx->d_full_rec);
+                if (ctx->d_full_ids) { (void)hipFree(ctx->d_full_ids); ctx->d_full_ids = nullptr; }
+                ctx->cap_full_rec = 0;
+                HIP_TRY(ctx, hipMalloc(&ctx->d_full_rec, full_bytes));
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_full_ids, n_full * sizeof(uint32_t)));
+                ctx->cap_full_rec = full_bytes;
+            }
+            if (!ctx->d_full_counts) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_full_counts, 2 * sizeof(uint32_t)));
+        }
+    }
+
     for (int k = 0; k < 3; ++k) { p.eye[k] = s->eye[k]; p.u[k] = s->u[k]; p.v[k] = s->v[k]; p.w[k] = s->w[k]; }
     p.left = s->left; p.right = s->right; p.top = s->top; p.bottom = s->bottom;
     // viewport::to_struct (gfxraytrace.hpp:736-740) stores the resolution as floats.
@@ -858,30 +560,43 @@ static int rebuild_view(mrt_ctx* ctx) {
         }
     }
     p.xres = s->xres; p.yres = s->yres;
-    p.n_tri_padded = (uint32_t)(filt.size() / 3);
-    p.n_sph_padded = (uint32_t)sfilt.size();
+    p.n_tri_padded = n_tri_padded;
+    p.n_sph_padded = n_sph_padded;
     p.sph_filter = (const float4*)ctx->d_sph_filter;
     p.tri_filter = (const float4*)ctx->d_tri_filter;
     p.tri_circle = (const float4*)ctx->d_tri_circle;
     ctx->projection = s->projection;
 
-    if (ctx->flags & MRT_FLAG_FULL_TEST) {
-        // Records of full_trace_kernel, made on the device so that they carry the device's own
-        // roundings.  One chunk of slack: the kernel stages whole LDS chunks from wherever a sign
-        // group starts (it never tests what lies beyond the group).
-        const size_t n_rec = (size_t)round_up(s->n_tris ? s->n_tris : 1, mrt::kChunkTris) + mrt::kChunkTris;
-        const size_t bytes = n_rec * mrt::kFullRecFloat4 * sizeof(float4);
-        if (!ctx->d_full_rec || ctx->cap_full_rec != bytes) {
-            free_dev(ctx->d_full_rec);
-            if (ctx->d_full_ids) { (void)hipFree(ctx->d_full_ids); ctx->d_full_ids = nullptr; }
-            ctx->cap_full_rec = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->d_full_rec, bytes));
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_full_ids, n_rec * sizeof(uint32_t)));
-            ctx->cap_full_rec = bytes;
-        }
-        if (!ctx->d_full_counts) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_full_counts, 2 * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_full_rec, 0, bytes, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_full_ids, 0, n_rec * sizeof(uint32_t), ctx->stream));
+    // The view as the record kernels see it.
+    mrt::ViewDerived w{};
+    for (int k = 0; k < 3; ++k) { w.eye[k] = s->eye[k]; w.u[k] = s->u[k]; w.v[k] = s->v[k]; w.w[k] = s->w[k]; }
+    w.focal = s->focal;
+    w.xres = s->xres; w.yres = s->yres;
+    // uv(px) = u0 + u1*px for 0-based pixel index px (kernel.cl:126-127 with pos = px + 1);
+    // (right-left) is a float subtraction in the reference.
+    w.ux1 = (double)(float)(s->right - s->left) / (double)(float)s->xres;
+    w.uy1 = (double)(float)(s->top - s->bottom) / (double)(float)s->yres;
+    w.ux0 = (double)s->left + 1.5 * w.ux1;
+    w.uy0 = (double)s->bottom + 1.5 * w.uy1;
+    w.mux = std::fmax(std::fabs(w.ux0), std::fabs(w.ux0 + w.ux1 * (w.xres - 1)));
+    w.muy = std::fmax(std::fabs(w.uy0), std::fabs(w.uy0 + w.uy1 * (w.yres - 1)));
+    w.persp = s->projection == MRT_PROJ_PERSP;
+    {
+        auto dot3d = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+        const double tol = 1e-4;
+        w.orthonormal = std::fabs(dot3d(w.u, w.u) - 1) < tol && std::fabs(dot3d(w.v, w.v) - 1) < tol &&
+                        std::fabs(dot3d(w.w, w.w) - 1) < tol && std::fabs(dot3d(w.u, w.v)) < tol &&
+                        std::fabs(dot3d(w.u, w.w)) < tol && std::fabs(dot3d(w.v, w.w)) < tol;
+    }
+    hipLaunchKernelGGL(mrt::build_triangle_records, dim3((n_tri_padded + 127) / 128), dim3(128), 0, ctx->stream, w,
+                       (const float4*)ctx->d_tri_exact, s->n_tris, n_tri_padded, (float4*)ctx->d_tri_filter,
+                       (float4*)ctx->d_tri_circle);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(mrt::build_sphere_records, dim3((n_sph_padded + 127) / 128), dim3(128), 0, ctx->stream, w,
+                       (const float4*)ctx->d_sph, s->n_spheres, n_sph_padded, (float4*)ctx->d_sph_filter);
+    HIP_TRY(ctx, hipGetLastError());
+
+    if (full) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_full_counts, 0, 2 * sizeof(uint32_t), ctx->stream));
         if (s->n_tris) {
             const dim3 g((s->n_tris + 255) / 256), b(256);
@@ -893,8 +608,10 @@ static int rebuild_view(mrt_ctx* ctx) {
                                    (float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts);
             HIP_TRY(ctx, hipGetLastError());
         }
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    // Frames on other streams wait for this event (launch_frame).
+    HIP_TRY(ctx, hipEventRecord(ctx->records_ready, ctx->stream));
+    ctx->records_pending = true;
     return MRT_OK;
 }
 
@@ -909,20 +626,12 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->have_scene = false;
 
-    // Host copy of the header and of the geometry planes.
+    // Host copy of the header; the plane pointers are the caller's and are not kept.
     ctx->h_scene = *s;
-    for (int k = 0; k < 9; ++k) {
-        ctx->h_tri[k].assign(s->n_tris ? s->tri[k] : nullptr, s->n_tris ? s->tri[k] + s->n_tris : nullptr);
-        ctx->h_scene.tri[k] = ctx->h_tri[k].data();
-    }
-    for (int k = 0; k < 4; ++k) {
-        ctx->h_sph[k].assign(s->n_spheres ? s->sph[k] : nullptr, s->n_spheres ? s->sph[k] + s->n_spheres : nullptr);
-        ctx->h_scene.sph[k] = ctx->h_sph[k].data();
-    }
-    // Not needed for the per-view records; never dereferenced through h_scene.
-    ctx->h_scene.sph_mat = nullptr; ctx->h_scene.tri_mat = nullptr;
-    for (int k = 0; k < 4; ++k) ctx->h_scene.mat[k] = nullptr;
+    for (int k = 0; k < 9; ++k) ctx->h_scene.tri[k] = nullptr;
+    for (int k = 0; k < 4; ++k) { ctx->h_scene.sph[k] = nullptr; ctx->h_scene.mat[k] = nullptr; }
     for (int k = 0; k < 6; ++k) ctx->h_scene.light[k] = nullptr;
+    ctx->h_scene.sph_mat = nullptr; ctx->h_scene.tri_mat = nullptr;
 
     std::vector<float4> exact((size_t)s->n_tris * 3);
     for (uint32_t k = 0; k < s->n_tris; ++k) {
@@ -967,8 +676,9 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     p.mats = (const float4*)ctx->d_mats;
     p.lights = (const float4*)ctx->d_lights;
 
-    if ((rc = rebuild_view(ctx)) != MRT_OK) return rc;     // synchronises the stream
+    if ((rc = rebuild_view(ctx, true)) != MRT_OK) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    // The staging vectors above are pageable and die with this call.
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
@@ -986,9 +696,10 @@ int mrt_set_camera(mrt_ctx* ctx, const mrt_camera* cam) {
     if (cam->projection != MRT_PROJ_ORTHO && cam->projection != MRT_PROJ_PERSP)
         return fail(ctx, MRT_ERR_INVALID, "unknown projection");
     ENTER_DEVICE(ctx);
-    // Frames already enqueued on any stream still read the old records.
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    ctx->frame_pending = false;
+    // Asynchronous: the record kernels run on the ctx's stream behind the last frame enqueued
+    // (which still reads the old records, on whatever stream), and the next frame waits for them.
+    if (ctx->frame_pending && ctx->last_stream != ctx->stream)
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->frame_done, 0));
     mrt_scene& h = ctx->h_scene;
     for (int k = 0; k < 3; ++k) { h.eye[k] = cam->eye[k]; h.u[k] = cam->u[k]; h.v[k] = cam->v[k]; h.w[k] = cam->w[k]; }
     h.xres = cam->xres; h.yres = cam->yres;
@@ -996,7 +707,7 @@ int mrt_set_camera(mrt_ctx* ctx, const mrt_camera* cam) {
     h.projection = cam->projection;
     h.focal = cam->focal;
     ctx->have_scene = false;
-    int rc = rebuild_view(ctx);
+    int rc = rebuild_view(ctx, false);
     if (rc != MRT_OK) return rc;
     ctx->have_scene = true;
     return MRT_OK;

@@ -75,4 +75,17 @@ struct RenderParams {
     unsigned long long* exact_counter;  // optional
 };
 
+// What the record-building kernels (mrt_records.hip) need to know about a view, in double:
+// the camera, and the affine map from the 0-based pixel index to uv (kernel.cl:126-127 with the
+// pixel grid (x + 1, y + 1) of gfxraytrace.hpp:850-852): uv(px) = ux0 + ux1 * px.
+struct ViewDerived {
+    double eye[3], u[3], v[3], w[3];
+    double focal;
+    double ux0, ux1, uy0, uy1;
+    double mux, muy;              // largest |uv.x|, |uv.y| over the image
+    double xres, yres;
+    int32_t persp;
+    int32_t orthonormal;          // the basis is orthonormal to 1e-4 (the sphere outlines assume it)
+};
+
 }  // namespace mrt

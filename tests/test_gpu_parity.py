@@ -505,6 +505,28 @@ def test_set_camera_equals_fresh_scene(mrt, oracle):
             o = oracle.render(sc, threads=8)
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
             assert np.array_equal(a[1], o["ids"]) and np.array_equal(a[2], o["t"])
+        # mrt_set_camera does not wait: views and frames enqueued back to back, the frames on a
+        # stream that is not the context's own, each into its own buffer; every frame must show its view
+        import torch
+        views = [_random_scene(mrt, rng, mrt.PROJ_PERSP if k % 2 else mrt.PROJ_ORTHO, 160, 120, 1, 1) for k in range(6)]
+        side = torch.cuda.Stream()
+        bufs = [torch.zeros(160 * 120 * 4, dtype=torch.uint8, device="cuda:0") for _ in views]
+        torch.cuda.synchronize()
+        for view, buf in zip(views, bufs):
+            ctx.set_camera(view)
+            ctx.render_bands_device(120, 0, 1, buf.data_ptr(), buf.numel(), stream=side.cuda_stream)
+        torch.cuda.synchronize()
+        for view, buf in zip(views, bufs):
+            st = view.struct
+            sc = mrt.Scene(eye=list(st.eye), u=list(st.u), v=list(st.v), w=list(st.w), xres=160, yres=120,
+                           left=st.left, right=st.right, top=st.top, bottom=st.bottom, projection=st.projection,
+                           focal=st.focal, shader=base.struct.shader, ka=base.struct.ka, kd=base.struct.kd,
+                           ks=base.struct.ks, ambient=list(base.struct.ambient),
+                           background=list(base.struct.background), sph=base.sph, sph_mat=base.sph_mat,
+                           tri=base.tri, tri_mat=base.tri_mat, mat=base.mat, light=base.light)
+            fresh.set_scene(sc)
+            want, _ = fresh.render()
+            assert np.array_equal(buf.cpu().numpy().reshape(120, 160, 4), want)
     finally:
         ctx.close()
         fresh.close()
