@@ -259,6 +259,38 @@ def set_camera_cost(env, sc, reps=50):
             "primitives": sc.struct.n_spheres + sc.struct.n_tris}
 
 
+def native_multi_gpu(env, mkscene, world):
+    """The library's own single-process multi-GPU path (mrt_multi_*: one context and stream per
+    GPU, bands gathered to GPU 0 with RCCL, band-wise copies to the host image) through the
+    mrraytracer binary, as a child process of rank 0 while the other ranks wait: the 7680x4320
+    teatime frame and the 16384^2 soup on `world` GPUs.  Frame time includes the copy of the
+    image to page-locked host memory (unlike `value`).  A failure is reported, not raised."""
+    import subprocess
+    cli = ROOT / "opencl-raytracing_amd" / "mrraytracer"
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for key, text in (("teatime8k", mkscene.teatime(7680, 4320)), ("soup16k", mkscene.soup(16384, 16384))):
+            scene, png = Path(d) / f"{key}.json", Path(d) / f"{key}.png"
+            scene.write_text(text)
+            child_env = dict(os.environ, MRT_GPUS=str(world), MRT_STATS="1", MRT_REPEAT="5")
+            if env.rehearsal:
+                child_env["MRT_GPU_LIST"] = ",".join(["0"] * world)
+            elif world == 1:
+                child_env["MRT_GPU_LIST"] = "0"          # one rank through the same multi-GPU code
+            try:
+                r = subprocess.run([str(cli), str(scene), str(png)], capture_output=True, text=True,
+                                   env=child_env, timeout=240)
+                if r.returncode != 0:
+                    res[key] = {"error": r.stderr.strip()[-300:]}
+                    continue
+                st = json.loads(r.stderr.strip().splitlines()[-1])
+                res[key] = {k: st[k] for k in ("n_gpus", "gather", "note", "render_ms_max", "render_ms_sum",
+                                               "best_frame_ms", "mrays_per_s", "png_ms", "total_ms")}
+            except Exception as e:            # noqa: BLE001 -- a report, never a crash of the benchmark
+                res[key] = {"error": repr(e)[:300]}
+    return res
+
+
 def host_frame(env, job, total_rays):
     """What the CLI pays on top of the kernels: D2H into page-locked host memory (mrt_host_alloc,
     as the CLI does) and into ordinary pageable memory, then the PNG encode."""
@@ -416,6 +448,14 @@ def main():
                     out[f"{key}_ms_per_frame"] = sec[name]["ms_per_frame"]
                     out[f"{key}_mrays_per_s"] = sec[name]["mrays_per_s"]
                     out[f"{key}_scaling"] = "strong"
+    if rank == 0 and not args.no_secondary:
+        nat = native_multi_gpu(env, mkscene, world)
+        out["native_multi_gpu"] = nat
+        for key, e in nat.items():
+            if "best_frame_ms" in e:
+                out[f"native_{key}_frame_ms"] = e["best_frame_ms"]
+                out[f"native_{key}_mrays_per_s"] = e["mrays_per_s"]
+                out[f"native_{key}_gather"] = e["gather"]
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sc)

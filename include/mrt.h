@@ -250,6 +250,58 @@ int mrt_bands_to_image(const uint8_t *gathered, size_t stride_bytes, uint32_t xr
                        uint32_t band_rows, uint32_t world, uint8_t *image_out);
 
 /* ------------------------------------------------------------------------
+ * One frame over several GPUs of a node, from one process.  The image is cut
+ * into the interleaved row bands of mrt_band_rows, every GPU holds the whole
+ * scene and renders its own bands on its own stream, all GPUs at once, and the
+ * bands end up in one scanline-ordered host image.  Takes the place of the
+ * reference's single-device choice (CLHelpers.hpp:28-45) and of its host-side
+ * image assembly (gfxraytrace.hpp:872-875).
+ * ---------------------------------------------------------------------- */
+enum {
+    MRT_GATHER_AUTO = 0,   /* RCCL when there are several distinct GPUs and it loads, else PEER   */
+    MRT_GATHER_RCCL = 1,   /* ncclGather to rank 0 over xGMI, then rank 0 copies to the host      */
+    MRT_GATHER_PEER = 2,   /* hipMemcpyPeerAsync to rank 0, then rank 0 copies to the host        */
+    MRT_GATHER_HOST = 3    /* no gather: every GPU copies its own bands to the host image itself  */
+};
+
+typedef struct mrt_multi_config {
+    uint32_t n_gpus;          /* ranks; 0 = one per visible GPU                                   */
+    const int32_t *devices;   /* n_gpus HIP ordinals, NULL = 0 .. n_gpus-1.  An ordinal may repeat:
+                                 several ranks then share a GPU (a rehearsal of N ranks on fewer
+                                 GPUs; RCCL cannot be used then)                                  */
+    uint32_t flags;           /* MRT_FLAG_* for every rank                                        */
+    uint32_t band_rows;       /* rows per band, 0 = 64                                            */
+    uint32_t gather;          /* MRT_GATHER_*                                                     */
+} mrt_multi_config;
+
+typedef struct mrt_multi_stats {
+    double render_ms_max;   /* device time of the slowest rank's render kernels (HIP events)  */
+    double render_ms_sum;   /* ... summed over the ranks                                      */
+    double total_ms;        /* host wall time of the call: render, gather, copies to the host */
+    uint64_t rays, prim_tests;
+    uint32_t n_gpus;        /* ranks                                                          */
+    uint32_t gather;        /* MRT_GATHER_* actually used                                     */
+} mrt_multi_stats;
+
+typedef struct mrt_multi mrt_multi;
+
+int mrt_multi_create(const mrt_multi_config *cfg, mrt_multi **out);
+void mrt_multi_destroy(mrt_multi *m);
+/* Text of the last error on m (of the last failed mrt_multi_create when m is NULL). */
+const char *mrt_multi_last_error(const mrt_multi *m);
+/* Ranks, the gather transport in use, and a remark when MRT_GATHER_AUTO had to
+ * settle for less than RCCL (empty otherwise). */
+uint32_t mrt_multi_world(const mrt_multi *m);
+uint32_t mrt_multi_gather(const mrt_multi *m);
+const char *mrt_multi_note(const mrt_multi *m);
+/* mrt_set_scene / mrt_set_camera on every rank. */
+int mrt_multi_set_scene(mrt_multi *m, const mrt_scene *scene);
+int mrt_multi_set_camera(mrt_multi *m, const mrt_camera *camera);
+/* mrt_render_rgba8 over all ranks: same bytes as one GPU renders.  host_out is
+ * best page-locked (mrt_host_alloc): the band copies then run asynchronously. */
+int mrt_multi_render_rgba8(mrt_multi *m, uint8_t *host_out, mrt_multi_stats *stats /* may be NULL */);
+
+/* ------------------------------------------------------------------------
  * Scene files.  Same schema, validation order and error strings as the
  * reference loader (rayson.hpp:380-638) and the conversion that follows it
  * (gfxraytrace.hpp:645-721, camera basis in double :881-889).

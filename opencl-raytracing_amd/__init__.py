@@ -5,9 +5,10 @@ the ``mrraytracer`` command-line driver built from ``csrc/`` and ``host/``;
 this package only binds the ABI with ctypes for tests and benchmarks.
 """
 from .capi import (  # noqa: F401
-    MrtError, Context, LoadedScene, Scene, Stats, lib, lib_path, band_rows, bands_to_image,
+    MrtError, Context, MultiContext, MultiStats, LoadedScene, Scene, Stats, lib, lib_path, band_rows, bands_to_image,
     write_png_rgb, host_array, FLAG_NONE, FLAG_NO_PREFILTER, FLAG_COUNT_EXACT, FLAG_BLOCK_REJECT, FLAG_NO_CIRCLE,
     FLAG_SCREEN_CULL, FLAG_FULL_TEST, PROJ_ORTHO, PROJ_PERSP,
     SHADER_FLAT, SHADER_PHONG, CL_DTYPES, SceneStruct, EXPORTED_SYMBOLS, ABI_VERSION, NOALLOC_MAX_KEYS,
     KERNEL_TRACE, KERNEL_TRACE_BLOCK, KERNEL_CULL, KERNEL_FULL,
+    GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST,
 )

@@ -36,7 +36,10 @@ EXPORTED_SYMBOLS = [
     "mrt_stage_ortho_viewrays", "mrt_stage_persp_viewrays", "mrt_stage_intersect",
     "mrt_stage_flat_shader", "mrt_stage_phong_shader", "mrt_host_alloc", "mrt_host_free",
     "mrt_render_bands_device_noalloc",
+    "mrt_multi_create", "mrt_multi_destroy", "mrt_multi_last_error", "mrt_multi_world", "mrt_multi_gather",
+    "mrt_multi_note", "mrt_multi_set_scene", "mrt_multi_set_camera", "mrt_multi_render_rgba8",
 ]
+GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST = 0, 1, 2, 3
 NOALLOC_MAX_KEYS = 8 * 1024 * 1024
 
 _fp = C.POINTER(C.c_float)
@@ -84,6 +87,18 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class MultiConfigStruct(C.Structure):
+    """mrt_multi_config."""
+    _fields_ = [("n_gpus", C.c_uint32), ("devices", C.POINTER(C.c_int32)), ("flags", C.c_uint32),
+                ("band_rows", C.c_uint32), ("gather", C.c_uint32)]
+
+
+class MultiStats(C.Structure):
+    """mrt_multi_stats."""
+    _fields_ = [("render_ms_max", C.c_double), ("render_ms_sum", C.c_double), ("total_ms", C.c_double),
+                ("rays", C.c_uint64), ("prim_tests", C.c_uint64), ("n_gpus", C.c_uint32), ("gather", C.c_uint32)]
 
 
 class SceneInfoStruct(C.Structure):
@@ -176,6 +191,20 @@ def lib():
     L.mrt_render_bands_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp,
                                           C.POINTER(Stats)]
     L.mrt_render_bands_device_noalloc.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
+    L.mrt_multi_create.argtypes = [C.POINTER(MultiConfigStruct), C.POINTER(vp)]
+    L.mrt_multi_destroy.argtypes = [vp]
+    L.mrt_multi_destroy.restype = None
+    L.mrt_multi_last_error.argtypes = [vp]
+    L.mrt_multi_last_error.restype = C.c_char_p
+    L.mrt_multi_note.argtypes = [vp]
+    L.mrt_multi_note.restype = C.c_char_p
+    L.mrt_multi_world.argtypes = [vp]
+    L.mrt_multi_world.restype = C.c_uint32
+    L.mrt_multi_gather.argtypes = [vp]
+    L.mrt_multi_gather.restype = C.c_uint32
+    L.mrt_multi_set_scene.argtypes = [vp, C.POINTER(SceneStruct)]
+    L.mrt_multi_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
+    L.mrt_multi_render_rgba8.argtypes = [vp, vp, C.POINTER(MultiStats)]
     L.mrt_bands_to_image.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.mrt_scene_load_file.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.mrt_scene_load_text.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp), C.c_char_p, C.c_size_t]
@@ -405,6 +434,64 @@ class Context:
     def close(self):
         if self._h:
             lib().mrt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiContext:
+    """mrt_multi: one frame over several GPUs (or several ranks sharing GPUs) from this process."""
+
+    def __init__(self, devices=None, n_gpus=0, flags=FLAG_NONE, band_rows_=0, gather=GATHER_AUTO):
+        L = lib()
+        self._h = C.c_void_p()
+        cfg = MultiConfigStruct()
+        if devices is not None:
+            self._devs = (C.c_int32 * len(devices))(*devices)
+            cfg.n_gpus, cfg.devices = len(devices), self._devs
+        else:
+            cfg.n_gpus, cfg.devices = n_gpus, None
+        cfg.flags, cfg.band_rows, cfg.gather = flags, band_rows_, gather
+        rc = L.mrt_multi_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise MrtError(rc, L.mrt_multi_last_error(None).decode())
+        self.world = L.mrt_multi_world(self._h)
+        self.gather = L.mrt_multi_gather(self._h)
+        self.note = L.mrt_multi_note(self._h).decode()
+        self.xres = self.yres = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MrtError(rc, lib().mrt_multi_last_error(self._h).decode())
+
+    def set_scene(self, scene):
+        st = scene.struct
+        self._check(lib().mrt_multi_set_scene(self._h, C.byref(st)))
+        self.xres, self.yres = st.xres, st.yres
+
+    def set_camera(self, scene):
+        st = scene.struct
+        cam = CameraStruct()
+        for name in ("eye", "u", "v", "w", "xres", "yres", "left", "right", "top", "bottom", "projection", "focal"):
+            setattr(cam, name, getattr(st, name))
+        self._check(lib().mrt_multi_set_camera(self._h, C.byref(cam)))
+        self.xres, self.yres = st.xres, st.yres
+
+    def render(self, out=None):
+        stats = MultiStats()
+        img = np.empty((self.yres, self.xres, 4), np.uint8) if out is None else out
+        if img.shape != (self.yres, self.xres, 4) or img.dtype != np.uint8 or not img.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of shape (yres, xres, 4)")
+        self._check(lib().mrt_multi_render_rgba8(self._h, img.ctypes.data, C.byref(stats)))
+        return img, stats
+
+    def close(self):
+        if self._h:
+            lib().mrt_multi_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -7,12 +7,19 @@
 // is no CPU fallback -- without a usable GPU the render step fails with the
 // library's error text and exit status 1.
 //
-// MRT_STATS=1 in the environment adds one JSON line with timings on stderr.
+// Environment (all optional; the two positional arguments are the whole contract):
+//   MRT_STATS=1        one JSON line with timings on stderr
+//   MRT_FLAGS=<int>    mrt_config.flags: one of the library's other kernels, same pixels
+//   MRT_GPUS=<n|all>   render on n GPUs of this node at once (interleaved row bands, mrt_multi_*)
+//   MRT_GPU_LIST=a,b,. the HIP ordinals of the ranks instead of 0 .. n-1; an ordinal may repeat
+//   MRT_GATHER=rccl|peer|host   how the bands reach the host image (default: RCCL if it can)
+//   MRT_REPEAT=<k>     render the frame k more times and report the fastest (with MRT_STATS)
 #include "mrt.h"
 
 #include <cstdio>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -89,25 +96,74 @@ int main(int argc, char** argv) {
     print_scene(*scene, *mrt_scene_info_view(loaded));
 
     std::cout << "raytracing..." << std::flush;
-    mrt_ctx* ctx = nullptr;
-    mrt_config cfg = {-1, MRT_FLAG_NONE};
-    // MRT_FLAGS=<integer> selects one of the library's other kernels (mrt.h, mrt_flags); same pixels.
-    if (const char* f = std::getenv("MRT_FLAGS")) cfg.flags = static_cast<uint32_t>(std::strtoul(f, nullptr, 0));
+    uint32_t flags = MRT_FLAG_NONE;
+    if (const char* f = std::getenv("MRT_FLAGS")) flags = static_cast<uint32_t>(std::strtoul(f, nullptr, 0));
+    // How many GPUs, and which.
+    std::vector<int32_t> gpu_list;
+    if (const char* l = std::getenv("MRT_GPU_LIST")) {
+        for (const char* q = l; *q;) {
+            char* end = nullptr;
+            const long v = std::strtol(q, &end, 10);
+            if (end == q) break;
+            gpu_list.push_back(static_cast<int32_t>(v));
+            q = (*end == ',') ? end + 1 : end;
+        }
+    }
+    uint32_t n_gpus = gpu_list.empty() ? 1u : static_cast<uint32_t>(gpu_list.size());
+    bool multi = !gpu_list.empty();
+    if (const char* g = std::getenv("MRT_GPUS")) {
+        if (gpu_list.empty()) n_gpus = std::strcmp(g, "all") == 0 ? 0u : static_cast<uint32_t>(std::strtoul(g, nullptr, 10));
+        multi = multi || n_gpus != 1;
+    }
+    uint32_t gather = MRT_GATHER_AUTO;
+    if (const char* g = std::getenv("MRT_GATHER")) {
+        if (!std::strcmp(g, "rccl")) gather = MRT_GATHER_RCCL;
+        else if (!std::strcmp(g, "peer")) gather = MRT_GATHER_PEER;
+        else if (!std::strcmp(g, "host")) gather = MRT_GATHER_HOST;
+    }
+    int repeat = 0;
+    if (const char* r = std::getenv("MRT_REPEAT")) repeat = std::atoi(r);
+
     const size_t n_bytes = static_cast<size_t>(scene->xres) * scene->yres * 4;
-    mrt_stats stats;
+    mrt_stats stats{};
+    mrt_multi_stats mstats{};
+    mrt_ctx* ctx = nullptr;
+    mrt_multi* mctx = nullptr;
     void* pinned = nullptr;
+    double best_ms = 0.0;
     const auto t_create = clk::now();
-    int rc = mrt_create(&cfg, &ctx);
+    int rc;
+    if (multi) {
+        mrt_multi_config mc = {n_gpus, gpu_list.empty() ? nullptr : gpu_list.data(), flags, 0u, gather};
+        rc = mrt_multi_create(&mc, &mctx);
+    } else {
+        mrt_config cfg = {-1, flags};
+        rc = mrt_create(&cfg, &ctx);
+    }
     if (rc == MRT_OK) rc = mrt_host_alloc(n_bytes, &pinned);
-    const double create_ms = ms_since(t_create);       // HIP start-up, stream, page-locked frame buffer
+    const double create_ms = ms_since(t_create);       // HIP start-up, streams, page-locked frame buffer
     uint8_t* pixels = static_cast<uint8_t*>(pinned);
-    if (rc == MRT_OK) rc = mrt_set_scene(ctx, scene);
-    if (rc == MRT_OK) rc = mrt_render_rgba8(ctx, pixels, &stats);
-    if (rc != MRT_OK) {
-        std::cerr << std::endl << "error: render failed: " << mrt_last_error(ctx) << std::endl;
+    auto render_once = [&]() {
+        return multi ? mrt_multi_render_rgba8(mctx, pixels, &mstats) : mrt_render_rgba8(ctx, pixels, &stats);
+    };
+    if (rc == MRT_OK) rc = multi ? mrt_multi_set_scene(mctx, scene) : mrt_set_scene(ctx, scene);
+    if (rc == MRT_OK) rc = render_once();
+    for (int k = 0; k < repeat && rc == MRT_OK; ++k) {
+        const auto t_frame = clk::now();
+        rc = render_once();
+        const double ms = ms_since(t_frame);
+        if (k == 0 || ms < best_ms) best_ms = ms;
+    }
+    auto cleanup = [&]() {
         mrt_host_free(pinned);
         mrt_destroy(ctx);
+        mrt_multi_destroy(mctx);
         mrt_scene_free(loaded);
+    };
+    if (rc != MRT_OK) {
+        const char* why = multi ? mrt_multi_last_error(mctx) : mrt_last_error(ctx);
+        std::cerr << std::endl << "error: render failed: " << why << std::endl;
+        cleanup();
         return 1;
     }
     std::cout << "done" << std::endl;
@@ -116,9 +172,7 @@ int main(int argc, char** argv) {
     const auto t_png = clk::now();
     if (mrt_write_png_rgb(output_path.c_str(), pixels, scene->xres, scene->yres) != MRT_OK) {
         std::cerr << std::endl << "error: could not write PNG" << std::endl;
-        mrt_host_free(pinned);
-        mrt_destroy(ctx);
-        mrt_scene_free(loaded);
+        cleanup();
         return 1;
     }
     std::cout << "done" << std::endl << std::endl;
@@ -126,16 +180,26 @@ int main(int argc, char** argv) {
 
     const char* want = std::getenv("MRT_STATS");
     if (want && want[0] == '1') {
-        std::fprintf(stderr,
-                     "{\"rays\": %llu, \"prim_tests\": %llu, \"load_ms\": %.3f, \"create_ms\": %.3f, "
-                     "\"upload_ms\": %.4f, \"trace_ms\": %.4f, \"shade_ms\": %.4f, \"download_ms\": %.4f, "
-                     "\"png_ms\": %.3f, \"total_ms\": %.3f, \"mrays_per_s\": %.2f}\n",
-                     (unsigned long long)stats.rays, (unsigned long long)stats.prim_tests, load_ms, create_ms,
-                     stats.upload_ms, stats.trace_ms, stats.shade_ms, stats.download_ms, png_ms, ms_since(t_start),
-                     stats.kernel_ms > 0 ? stats.rays / stats.kernel_ms * 1e-3 : 0.0);
+        const unsigned long long rays = static_cast<unsigned long long>(scene->xres) * scene->yres;
+        if (multi) {
+            static const char* const names[] = {"auto", "rccl", "peer", "host"};
+            std::fprintf(stderr,
+                         "{\"rays\": %llu, \"n_gpus\": %u, \"gather\": \"%s\", \"note\": \"%s\", \"load_ms\": %.3f, "
+                         "\"create_ms\": %.3f, \"render_ms_max\": %.4f, \"render_ms_sum\": %.4f, \"frame_ms\": %.4f, "
+                         "\"best_frame_ms\": %.4f, \"png_ms\": %.3f, \"total_ms\": %.3f, \"mrays_per_s\": %.2f}\n",
+                         rays, mstats.n_gpus, names[mstats.gather & 3u], mrt_multi_note(mctx), load_ms, create_ms,
+                         mstats.render_ms_max, mstats.render_ms_sum, mstats.total_ms, best_ms, png_ms,
+                         ms_since(t_start), (repeat > 0 && best_ms > 0) ? rays / best_ms * 1e-3 : rays / mstats.total_ms * 1e-3);
+        } else {
+            std::fprintf(stderr,
+                         "{\"rays\": %llu, \"prim_tests\": %llu, \"load_ms\": %.3f, \"create_ms\": %.3f, "
+                         "\"upload_ms\": %.4f, \"trace_ms\": %.4f, \"shade_ms\": %.4f, \"download_ms\": %.4f, "
+                         "\"best_frame_ms\": %.4f, \"png_ms\": %.3f, \"total_ms\": %.3f, \"mrays_per_s\": %.2f}\n",
+                         (unsigned long long)stats.rays, (unsigned long long)stats.prim_tests, load_ms, create_ms,
+                         stats.upload_ms, stats.trace_ms, stats.shade_ms, stats.download_ms, best_ms, png_ms,
+                         ms_since(t_start), stats.kernel_ms > 0 ? stats.rays / stats.kernel_ms * 1e-3 : 0.0);
+        }
     }
-    mrt_host_free(pinned);
-    mrt_destroy(ctx);
-    mrt_scene_free(loaded);
+    cleanup();
     return 0;
 }

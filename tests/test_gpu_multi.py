@@ -1,0 +1,132 @@
+"""mrt_multi_*: one frame over several ranks from one process, through the C ABI.
+
+On a one-GPU machine the ranks share GPU 0 (an ordinal may repeat in the device list), which
+exercises everything but the inter-GPU links: the band partition, one context, stream and buffer
+per rank, the PEER and HOST transports, and the band-by-band copies that de-interleave straight
+into the caller's image.  RCCL cannot place two ranks on one GPU; its call sequence
+(ncclCommInitAll, grouped ncclGather, in place on the root) runs with a single rank.  The bar:
+the bytes of the single-context frame, whatever the number of ranks and the transport.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENES, GOLDEN
+from parity import check
+
+sys.path.insert(0, str(ROOT / "tools"))
+import mkscene  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(mrt, sc, flags=0):
+    ctx = mrt.Context(device=0, flags=flags)
+    try:
+        ctx.set_scene(sc)
+        img, _ = ctx.render()
+    finally:
+        ctx.close()
+    return img
+
+
+@pytest.mark.parametrize("gather", ["peer", "host"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_multi_rank_frame_equals_single_context(mrt, world, gather):
+    kind = {"peer": mrt.GATHER_PEER, "host": mrt.GATHER_HOST}[gather]
+    sc = mrt.LoadedScene(text=mkscene.teatime(1280, 720)).copy()
+    want = _single(mrt, sc)
+    m = mrt.MultiContext(devices=[0] * world, gather=kind)
+    try:
+        assert m.world == world and m.gather == kind
+        m.set_scene(sc)
+        img, st = m.render()
+        assert np.array_equal(img, want)
+        assert st.n_gpus == world and st.rays == 1280 * 720 and st.render_ms_max > 0
+        # into page-locked memory, a second frame, then another view of another size
+        pinned = mrt.host_array((720, 1280, 4))
+        img2, _ = m.render(out=pinned)
+        assert np.array_equal(img2, want)
+        view = sc.with_resolution(999, 333)          # a short last band, rows not a multiple of 64
+        m.set_camera(view)
+        img3, _ = m.render()
+        assert np.array_equal(img3, _single(mrt, view))
+    finally:
+        m.close()
+
+
+def test_multi_auto_transport_and_flags(mrt):
+    sc = mrt.LoadedScene(text=mkscene.soup(640, 480, 4096, 256, seed=3)).copy()
+    want = _single(mrt, sc)
+    # AUTO with a repeated GPU cannot be RCCL: it settles for peer copies and says so
+    m = mrt.MultiContext(devices=[0, 0], band_rows_=16)
+    try:
+        assert m.gather == mrt.GATHER_PEER
+        m.set_scene(sc)
+        assert np.array_equal(m.render()[0], want)
+    finally:
+        m.close()
+    # the other kernels, rank by rank (bands of 32 rows keep the tile cull eligible)
+    for flags in (mrt.FLAG_FULL_TEST, mrt.FLAG_SCREEN_CULL, mrt.FLAG_BLOCK_REJECT):
+        m = mrt.MultiContext(devices=[0, 0, 0], flags=flags, band_rows_=32, gather=mrt.GATHER_HOST)
+        try:
+            m.set_scene(sc)
+            assert np.array_equal(m.render()[0], want), flags
+        finally:
+            m.close()
+    # RCCL asked for explicitly with a repeated GPU: refused with a reason
+    with pytest.raises(mrt.MrtError) as e:
+        mrt.MultiContext(devices=[0, 0], gather=mrt.GATHER_RCCL)
+    assert "RCCL" in e.value.message
+    with pytest.raises(mrt.MrtError):
+        mrt.MultiContext(devices=[0, 7])
+
+
+def test_multi_rccl_call_sequence_single_rank(mrt):
+    """One rank, transport RCCL: communicator from ncclCommInitAll, grouped in-place ncclGather
+    on the rank's stream, band copies behind it."""
+    sc = mrt.LoadedScene(text=mkscene.teatime(640, 360)).copy()
+    m = mrt.MultiContext(devices=[0], gather=mrt.GATHER_RCCL)
+    try:
+        assert m.gather == mrt.GATHER_RCCL
+        m.set_scene(sc)
+        for _ in range(3):
+            img, st = m.render()
+        assert st.gather == mrt.GATHER_RCCL
+        assert np.array_equal(img, _single(mrt, sc))
+    finally:
+        m.close()
+
+
+def test_cli_multi_gpu_writes_the_same_png(tmp_path):
+    """MRT_GPU_LIST=0,0 mrraytracer teatime.json out.png: the bytes of the single-GPU PNG."""
+    cli = ROOT / "opencl-raytracing_amd" / "mrraytracer"
+    scene = SCENES / "teatime.json"
+    one, two, host = tmp_path / "one.png", tmp_path / "two.png", tmp_path / "host.png"
+    r = subprocess.run([str(cli), str(scene), str(one)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, MRT_GPU_LIST="0,0", MRT_STATS="1", MRT_REPEAT="3")
+    r = subprocess.run([str(cli), str(scene), str(two)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.endswith(f"raytracing...done\nwriting {two}...done\n\n")
+    st = json.loads(r.stderr.strip().splitlines()[-1])
+    assert st["n_gpus"] == 2 and st["gather"] == "peer" and st["best_frame_ms"] > 0
+    assert two.read_bytes() == one.read_bytes()
+    env = dict(os.environ, MRT_GPU_LIST="0,0,0", MRT_GATHER="host")
+    r = subprocess.run([str(cli), str(scene), str(host)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert host.read_bytes() == one.read_bytes()
+    # one rank with the RCCL transport: the system's librccl, loaded by the binary itself
+    env = dict(os.environ, MRT_GPU_LIST="0", MRT_GATHER="rccl", MRT_STATS="1")
+    r = subprocess.run([str(cli), str(scene), str(host)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stderr.strip().splitlines()[-1])["gather"] == "rccl"
+    assert host.read_bytes() == one.read_bytes()
+    # a GPU that does not exist is an error, exit status 1
+    env = dict(os.environ, MRT_GPU_LIST="0,9")
+    r = subprocess.run([str(cli), str(scene), str(host)], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "render failed" in r.stderr
