@@ -39,7 +39,7 @@ __global__ void build_sphere_records(const ViewDerived w, const float4* sph, uin
 template <int PROJ>
 __global__ void shade_kernel(const RenderParams p, const float* t_in, const int32_t* id_in, uint32_t pitch);
 template <int PROJ>
-__global__ void shade_keys_kernel(const RenderParams p, const unsigned long long* key_plane, float* t_out,
+__global__ void shade_keys_kernel(const RenderParams p, unsigned long long* key_plane, float* t_out,
                                   int32_t* id_out, uint32_t pitch);
 }  // namespace mrt
 
@@ -114,6 +114,11 @@ struct mrt_ctx {
     int32_t* d_id = nullptr;
     unsigned long long* d_key = nullptr;     // trace_kernel's working plane: (t, id) keys under atomicMin
     size_t plane_elems = 0, key_elems = 0;
+    // Every key of d_key is "no hit" (all ones): sliced frames keep it so (shade_keys_kernel puts
+    // back what the frame wrote), which saves the memset; false after anything else touched it.
+    bool keys_clean = false;
+    uint32_t* d_tile_flags = nullptr;        // one word per 32x32 tile of the padded plane
+    size_t tile_flag_elems = 0;
     uint32_t* d_out = nullptr;
     size_t out_elems = 0;
     unsigned long long* d_counter = nullptr;
@@ -210,8 +215,17 @@ int ensure_keys(mrt_ctx* ctx, size_t elems) {
     if (elems <= ctx->key_elems) return MRT_OK;
     if (ctx->d_key) { (void)hipFree(ctx->d_key); ctx->d_key = nullptr; }
     ctx->key_elems = 0;
+    ctx->keys_clean = false;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_key, elems * sizeof(unsigned long long)));
     ctx->key_elems = elems;
+    ctx->keys_clean = false;
+    const size_t tiles = elems / (mrt::kWaveTile * mrt::kWaveTile);
+    if (tiles > ctx->tile_flag_elems) {
+        if (ctx->d_tile_flags) { (void)hipFree(ctx->d_tile_flags); ctx->d_tile_flags = nullptr; }
+        ctx->tile_flag_elems = 0;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_flags, tiles * sizeof(uint32_t)));
+        ctx->tile_flag_elems = tiles;
+    }
     return MRT_OK;
 }
 
@@ -345,8 +359,23 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         }
     }
     const dim3 zgrid(tgrid.x, tgrid.y, p.prim_slices);
-    if (p.prim_slices > 1)
+    p.tile_flags = nullptr;
+    p.tiles_x = pitch / mrt::kWaveTile;
+    const bool keeps_keys_clean = p.prim_slices > 1 && planes.own;
+    if (keeps_keys_clean) {
+        // The ctx's own key plane stays all "no hit" from frame to frame: shade_keys_kernel puts
+        // back every key this frame writes.  Only the tile flags (4 bytes per 1024 pixels) are
+        // cleared per frame.
+        if (!ctx->keys_clean)
+            HIP_TRY(ctx, hipMemsetAsync(d_key, 0xFF, ctx->key_elems * sizeof(unsigned long long), stream));
+        ctx->keys_clean = false;               // until this frame's shade_keys_kernel is enqueued
+        p.tile_flags = ctx->d_tile_flags;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_flags, 0, plane_elems / (mrt::kWaveTile * mrt::kWaveTile) * sizeof(uint32_t), stream));
+    } else if (p.prim_slices > 1) {
         HIP_TRY(ctx, hipMemsetAsync(d_key, 0xFF, plane_elems * sizeof(unsigned long long), stream));
+    } else if (d_key != nullptr && planes.own) {
+        ctx->keys_clean = false;               // a single-slice frame initialises and leaves its own keys
+    }
     uint32_t kernel;
     if (full && persp) {
         kernel = MRT_KERNEL_FULL;
@@ -378,12 +407,14 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     HIP_TRY(ctx, hipGetLastError());
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
     if (p.prim_slices > 1) {
-        const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
+        // with tile flags the launch covers the padded plane: padding pixels hold keys too
+        const dim3 sgrid(p.tile_flags ? pitch / 64 : (p.xres + 63) / 64, p.tile_flags ? prow / 4 : (p.local_rows + 3) / 4);
         if (persp)
             hipLaunchKernelGGL(mrt::shade_keys_kernel<MRT_PROJ_PERSP>, sgrid, dim3(256), 0, stream, p, d_key, d_t, d_id, pitch);
         else
             hipLaunchKernelGGL(mrt::shade_keys_kernel<MRT_PROJ_ORTHO>, sgrid, dim3(256), 0, stream, p, d_key, d_t, d_id, pitch);
         HIP_TRY(ctx, hipGetLastError());
+        if (keeps_keys_clean) ctx->keys_clean = true;
     } else if (!p.fuse_shade) {
         const dim3 sgrid((p.xres + 63) / 64, (p.local_rows + 3) / 4);
         if (persp)
@@ -482,6 +513,7 @@ void mrt_destroy(mrt_ctx* ctx) {
     if (ctx->d_t) (void)hipFree(ctx->d_t);
     if (ctx->d_id) (void)hipFree(ctx->d_id);
     if (ctx->d_key) (void)hipFree(ctx->d_key);
+    if (ctx->d_tile_flags) (void)hipFree(ctx->d_tile_flags);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     for (int k = 0; k < 3; ++k) if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);

@@ -164,7 +164,7 @@ template <int PROJ, bool TRI>
 __device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim, uint32_t total, int lane,
                                            const uint16_t* __restrict__ list, const float* __restrict__ tile_ux,
                                            const float* __restrict__ tile_uy, unsigned long long* __restrict__ keys,
-                                           uint32_t stride, unsigned long long& n_exact) {
+                                           uint32_t stride, unsigned long long& n_exact, bool& recorded) {
     F3 A, B, C;
     float radius = 0.0f;
     if (TRI) {
@@ -190,9 +190,11 @@ __device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim,
             // reference's loop only rejects what the minimum rejects too.
             if (TRI) hit = tri_exact(A, B, C, o, d, FLT_MAX, 0.0f, t);
             else hit = sphere_exact(A, radius, o, d, FLT_MAX, 0.0f, t, two);
-            if (hit && t > 0.0f && t < FLT_MAX)
+            if (hit && t > 0.0f && t < FLT_MAX) {
                 atomicMin(&keys[(size_t)(px >> 5) * stride + (px & 31u)],
                           ((unsigned long long)__float_as_uint(t) << 32) | obj_id);
+                recorded = true;
+            }
             ++n_exact;
         }
     }
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     // (the first __syncthreads() of the chunk loops below orders these writes before their use)
 
     unsigned long long n_exact = 0;
+    bool recorded = false;           // this lane recorded a hit in the key plane
     const bool no_prefilter = (p.flags & MRT_FLAG_NO_PREFILTER) != 0;
     const bool use_circle = (p.flags & (MRT_FLAG_NO_PREFILTER | MRT_FLAG_NO_CIRCLE)) == 0;
 
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                 if (no_prefilter) mask = 0xFFFFu;
                 if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
                 const uint32_t total = list_pixels(mask, bx, by, lane, list, list_count);
-                exact_list<PROJ, false>(p, si, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact);
+                exact_list<PROJ, false>(p, si, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact, recorded);
             }
         }
     }
@@ -480,13 +483,16 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                 if (no_prefilter) mask = 0xFFFFu;
                 if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
                 const uint32_t total = list_pixels(mask, bx, by, lane, list, list_count);
-                exact_list<PROJ, true>(p, ti, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact);
+                exact_list<PROJ, true>(p, ti, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact, recorded);
             }
         }
         }
     }
 
     if (wave_active && !single_slice) {
+        // tell shade_keys_kernel that this tile has keys worth reading (any wave of any slice may)
+        if (p.tile_flags != nullptr && __builtin_amdgcn_ballot_w64(recorded) != 0 && lane == 0)
+            p.tile_flags[(wave_lr0 / kWaveTile) * p.tiles_x + wave_x0 / kWaveTile] = 1u;
         if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
     } else if (wave_active) {
         // The atomics went to the device's L2; make sure the loads below see them.
@@ -590,6 +596,7 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     unsigned long long n_exact = 0;
+    bool recorded = false;
 
     // ---- spheres ----
     for (uint32_t base = 0; base < p.n_sph; base += 64) {
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
             }
             if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
             const uint32_t total = list_pixels(mask, bx, by, lane, list, &s_count[wave]);
-            exact_list<PROJ, false>(p, si, total, lane, list, tile_ux, tile_uy, keys, kWaveTile, n_exact);
+            exact_list<PROJ, false>(p, si, total, lane, list, tile_ux, tile_uy, keys, kWaveTile, n_exact, recorded);
         }
     }
 
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
             }
             if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
             const uint32_t total = list_pixels(mask, bx, by, lane, list, &s_count[wave]);
-            exact_list<PROJ, true>(p, ti, total, lane, list, tile_ux, tile_uy, keys, kWaveTile, n_exact);
+            exact_list<PROJ, true>(p, ti, total, lane, list, tile_ux, tile_uy, keys, kWaveTile, n_exact, recorded);
         }
     }
 
@@ -1099,18 +1106,29 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
 }
 
 // The epilogue of trace_kernel as a launch of its own, for frames traced in several slices: one
-// thread per pixel decodes the key, writes the (t, id) planes if asked to, and shades.  A key the host's
-// byte-wise initialisation left untouched is all ones: id -1, a miss.
+// thread per pixel of the padded plane decodes the key, writes the (t, id) planes if asked to, and
+// shades.  A key nobody touched is all ones: id -1, a miss.  With tile flags (see RenderParams)
+// the keys of a tile no wave recorded a hit in are not read at all, and every key that was
+// written -- padding pixels included, whose rows repeat the last image row -- is put back to all
+// ones, which leaves the plane ready for the next frame without a memset.
 template <int PROJ>
 __global__ __launch_bounds__(256) void shade_keys_kernel(const RenderParams p,
-                                                        const unsigned long long* __restrict__ key_plane,
+                                                        unsigned long long* __restrict__ key_plane,
                                                         float* __restrict__ t_out, int32_t* __restrict__ id_out,
                                                         uint32_t pitch) {
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
     const uint32_t lr = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= p.xres || lr >= p.local_rows) return;
+    const bool inside = x < p.xres && lr < p.local_rows;
+    if (p.tile_flags == nullptr && !inside) return;
     const size_t src = (size_t)lr * pitch + x;
-    const unsigned long long key = key_plane[src];
+    unsigned long long key = ~0ull;
+    if (p.tile_flags == nullptr) {
+        key = key_plane[src];
+    } else if (p.tile_flags[(lr / kWaveTile) * p.tiles_x + x / kWaveTile] != 0u) {
+        key = key_plane[src];
+        if (key != ~0ull) key_plane[src] = ~0ull;
+    }
+    if (!inside) return;
     const int32_t id = (int32_t)(uint32_t)key;
     const float t = id < 0 ? -1.0f : __uint_as_float((uint32_t)(key >> 32));     // kernel.cl:363
     if (t_out != nullptr) {
@@ -1146,8 +1164,8 @@ template __global__ void prep_full_records<MRT_PROJ_PERSP>(const RenderParams, f
 template __global__ void cull_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void cull_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, float*, int32_t*, uint32_t);
 
-template __global__ void shade_keys_kernel<MRT_PROJ_ORTHO>(const RenderParams, const unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void shade_keys_kernel<MRT_PROJ_PERSP>(const RenderParams, const unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void shade_keys_kernel<MRT_PROJ_ORTHO>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void shade_keys_kernel<MRT_PROJ_PERSP>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void shade_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float*, const int32_t*, uint32_t);
 template __global__ void shade_kernel<MRT_PROJ_PERSP>(const RenderParams, const float*, const int32_t*, uint32_t);
 

@@ -73,6 +73,11 @@ struct RenderParams {
     int32_t* ids;                   // optional, local_rows x xres
     float* tvals;                   // optional
     unsigned long long* exact_counter;  // optional
+    // Sliced trace_kernel frames with ctx-owned planes: one word per 32x32 wave tile, set by any
+    // wave that recorded a hit there, so that shade_keys_kernel reads (and puts back to "no hit")
+    // only the keys of tiles something hit.  nullptr: every key is read and none is put back.
+    uint32_t* tile_flags;
+    uint32_t tiles_x;               // tiles per row of the padded plane
 };
 
 // What the record-building kernels (mrt_records.hip) need to know about a view, in double:
