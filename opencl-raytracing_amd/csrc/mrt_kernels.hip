@@ -180,6 +180,7 @@ __device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim,
     const uint32_t obj_id = TRI ? p.n_sph + prim : prim;          // spheres first, gfxraytrace.hpp:701-714
     for (uint32_t b = 0; b < total; b += 64) {
         const uint32_t idx = b + (uint32_t)lane;
+        bool rec = false;
         if (idx < total) {
             const uint32_t px = list[idx];
             F3 o, d;
@@ -193,10 +194,12 @@ __device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim,
             if (hit && t > 0.0f && t < FLT_MAX) {
                 atomicMin(&keys[(size_t)(px >> 5) * stride + (px & 31u)],
                           ((unsigned long long)__float_as_uint(t) << 32) | obj_id);
-                recorded = true;
+                rec = true;
             }
             ++n_exact;
         }
+        // wave-uniform, so it lives in a scalar register
+        recorded = recorded || __builtin_amdgcn_ballot_w64(rec) != 0;
     }
 }
 
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     // (the first __syncthreads() of the chunk loops below orders these writes before their use)
 
     unsigned long long n_exact = 0;
-    bool recorded = false;           // this lane recorded a hit in the key plane
+    bool recorded = false;           // this wave recorded a hit in the key plane
     const bool no_prefilter = (p.flags & MRT_FLAG_NO_PREFILTER) != 0;
     const bool use_circle = (p.flags & (MRT_FLAG_NO_PREFILTER | MRT_FLAG_NO_CIRCLE)) == 0;
 
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
 
     if (wave_active && !single_slice) {
         // tell shade_keys_kernel that this tile has keys worth reading (any wave of any slice may)
-        if (p.tile_flags != nullptr && __builtin_amdgcn_ballot_w64(recorded) != 0 && lane == 0)
+        if (p.tile_flags != nullptr && recorded && lane == 0)
             p.tile_flags[(wave_lr0 / kWaveTile) * p.tiles_x + wave_x0 / kWaveTile] = 1u;
         if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
     } else if (wave_active) {
