@@ -112,11 +112,12 @@ class Job:
     rank 0.  Two buffer sets, so the gather of frame k overlaps the render of frame k+1."""
 
     def __init__(self, env, scene, flags=0):
+        """flags: MRT_FLAG_* of a brute-force context, or the name of an mrt_accel method."""
         import torch
         self.env, self.scene = env, scene
         st = scene.struct
         self.st = st
-        self.ctx = env.mrt.Context(device=env.dev_index, flags=flags)
+        self.ctx = env.mrt.renderer(device=env.dev_index, kind=flags)
         self.ctx.set_scene(scene)
         mrt, world = env.mrt, env.world
         self.rows = mrt.band_rows(st.yres, BAND_ROWS, env.rank, world)
@@ -205,6 +206,14 @@ def secondary_workloads(env, mkscene):
             e.update(extra)
         res[name] = e
 
+    def accel_extra(job):
+        """Grid statistics of an mrt_accel job (build time per view, cells, references)."""
+        if not isinstance(job.ctx, mrt.Accel) or job.ctx.method != mrt.ACCEL_GRID:
+            return None
+        s = job.ctx.render_bands_device(BAND_ROWS, env.rank, env.world, job.local[0].data_ptr(),
+                                        job.local[0].numel(), stream=env.stream.cuda_stream, timed=True)
+        return {"grid_build_ms_per_view": s.build_ms, "grid_cells": s.cells, "grid_refs": s.refs}
+
     # The 16384 x 16384 triangle soup, one frame split over all ranks (strong scaling).
     job = Job(env, mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy())
     frame_stats(job, "soup16k_16384x16384", steps=3, warmup=1, extra={"scaling": "strong"})
@@ -219,19 +228,22 @@ def secondary_workloads(env, mkscene):
             job = Job(env, mrt.LoadedScene(path=ROOT / "scenes" / f"{name}.json").copy())
             frame_stats(job, f"native_400x400_{name}", steps=20, warmup=2)
             job.close()
-        # The headline frame with parts of the rejection funnel switched off / the opt-in block form.
+        # The headline frame with parts of the rejection funnel switched off, and through the
+        # accelerated entry points (mrt_accel_*: not brute force, same pixels).
         sc4k = mrt.LoadedScene(text=mkscene.teatime(XRES, YRES)).copy()
         for label, flags, steps in (("teatime_4k_edge_test_only_no_circle", mrt.FLAG_NO_CIRCLE, 5),
                                     ("teatime_4k_exact_test_only_no_prefilter", mrt.FLAG_NO_PREFILTER, 2),
-                                    ("teatime_4k_opt_in_block_reject", mrt.FLAG_BLOCK_REJECT, 5),
-                                    ("teatime_4k_opt_in_screen_cull", mrt.FLAG_SCREEN_CULL, 5)):
+                                    ("teatime_4k_accel_block_reject", "block", 5),
+                                    ("teatime_4k_accel_tile_cull", "cull", 5),
+                                    ("teatime_4k_accel_grid", "grid", 20)):
             job = Job(env, sc4k, flags=flags)
-            frame_stats(job, label, steps=steps, warmup=1)
+            frame_stats(job, label, steps=steps, warmup=1, extra=accel_extra(job))
             job.close()
         soup = mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy()
-        job = Job(env, soup, flags=mrt.FLAG_SCREEN_CULL)
-        frame_stats(job, "soup16k_opt_in_screen_cull", steps=3, warmup=1)
-        job.close()
+        for label, method in (("soup16k_accel_tile_cull", "cull"), ("soup16k_accel_grid", "grid")):
+            job = Job(env, soup, flags=method)
+            frame_stats(job, label, steps=3, warmup=1, extra=accel_extra(job))
+            job.close()
         job = Job(env, soup, flags=mrt.FLAG_FULL_TEST)          # 4.7e12 pairs, about 3 s per frame
         frame_stats(job, "soup16k_full_test_every_pair", steps=1, warmup=0, kernel_reps=1)
         job.close()

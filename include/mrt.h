@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 2
+#define MRT_ABI_VERSION 3
 
 typedef enum mrt_status {
     MRT_OK = 0,
@@ -106,19 +106,12 @@ enum {
     /* Count the (pixel, primitive) pairs that reach the exact test into
      * mrt_stats.exact_tests (one atomic per wavefront; off by default). */
     MRT_FLAG_COUNT_EXACT = 1u << 1,
-    /* Opt-in screen-space culling, off by default: before the per-pixel
-     * prefilter, reject a triangle for a lane's whole 4x4 pixel block when one
-     * of its edge functions is negative over the entire block.  Same pixels
-     * out; the default path tests every pixel against every primitive. */
-    MRT_FLAG_BLOCK_REJECT = 1u << 2,
+    /* (bit 2 is reserved) */
     /* Skip the per-pixel bounding-circle test that precedes the per-pixel
      * edge-function test of a triangle (measurement aid; same pixels out). */
     MRT_FLAG_NO_CIRCLE = 1u << 3,
-    /* Opt-in screen-space culling, off by default: per 32x32 wave tile the
-     * lanes first test 64 primitives each against the whole tile and only the
-     * survivors are tested per block, per pixel and exactly.  Same pixels out.
-     * This is an acceleration, not the brute-force path the benchmark grades. */
-    MRT_FLAG_SCREEN_CULL = 1u << 4,
+    /* (bit 4 is reserved; screen-space culling is not a flag of this context but
+     * a separate entry-point family, mrt_accel_*, below) */
     /* No rejection in screen space at all: every (pixel, object) pair
      * evaluates the determinants of tri_intersect / the discriminant of
      * circle_intersect (kernel.cl:197-303) with the reference's own operation
@@ -141,13 +134,15 @@ typedef struct mrt_stats {
     uint32_t prim_slices;   /* grid layers the triangle list was cut into (trace kernel), else 1       */
 } mrt_stats;
 
-/* Which closest-hit kernel a frame ran (mrt_stats.kernel): the flags ask, the
- * band geometry decides (see MRT_FLAG_BLOCK_REJECT / MRT_FLAG_SCREEN_CULL). */
+/* Which closest-hit kernel a frame ran (mrt_stats.kernel).  A brute-force
+ * context runs TRACE or FULL; the others belong to mrt_accel_*, where the
+ * method asks and the band geometry decides (see mrt_accel_config). */
 enum {
     MRT_KERNEL_TRACE = 0,         /* per-pixel circle -> edge -> exact funnel (default)   */
     MRT_KERNEL_TRACE_BLOCK = 1,   /* ... preceded by the 4x4 block reject                 */
     MRT_KERNEL_CULL = 2,          /* 32x32 tile cull                                      */
-    MRT_KERNEL_FULL = 3           /* determinants for every pair (MRT_FLAG_FULL_TEST)     */
+    MRT_KERNEL_FULL = 3,          /* a 3x3 solve for every pair (MRT_FLAG_FULL_TEST)      */
+    MRT_KERNEL_GRID = 4           /* per-tile primitive lists of the screen-space grid    */
 };
 
 typedef struct mrt_ctx mrt_ctx;
@@ -233,8 +228,7 @@ int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uin
  * MRT_NOALLOC_MAX_KEYS 64-bit keys (64 MiB on every GPU the library has been
  * used on, until the process ends): the rows this rank renders, padded to
  * whole 64x64 pixel tiles, must fit -- a 3840x2160 frame does -- or the call
- * fails with MRT_ERR_TOO_LARGE.  Contexts created with MRT_FLAG_SCREEN_CULL
- * are refused (that kernel needs per-pixel planes of its own).  Every call on
+ * fails with MRT_ERR_TOO_LARGE.  Every call on
  * one GPU, from whatever ctx, shares that GPU's array: two such frames in
  * flight at once on one GPU race; enqueue them on one stream or synchronise
  * between them.  No counterpart in the reference, which allocates in every
@@ -300,6 +294,63 @@ int mrt_multi_set_camera(mrt_multi *m, const mrt_camera *camera);
 /* mrt_render_rgba8 over all ranks: same bytes as one GPU renders.  host_out is
  * best page-locked (mrt_host_alloc): the band copies then run asynchronously. */
 int mrt_multi_render_rgba8(mrt_multi *m, uint8_t *host_out, mrt_multi_stats *stats /* may be NULL */);
+
+/* ------------------------------------------------------------------------
+ * Screen-space acceleration: the same pixels without testing every pair.
+ *
+ * The reference's closest-hit loop is O(pixels x objects) (kernel.cl:320-360)
+ * and so is an mrt_ctx; the benchmark's tests/s are defined on that loop.  An
+ * mrt_accel is the algorithmic successor behind entry points of its own: it
+ * renders byte-identical frames (same winners, same t) but skips the pairs
+ * that cannot meet.  No counterpart in the reference.
+ * ---------------------------------------------------------------------- */
+enum {
+    /* Uniform grid over the image with cells of 32x32 pixels, built on the GPU
+     * for every view (mrt_accel_set_scene / _set_camera: bin count, exclusive
+     * scan, fill): each cell lists the objects whose conservative screen-space
+     * region touches it, and a frame walks one list per cell.  The build reads
+     * one word back, so those two calls wait for the GPU. */
+    MRT_ACCEL_GRID = 0,
+    /* No structure: every frame tests every object against every 32x32 tile
+     * (64 objects per wave instruction) and only the survivors per pixel. */
+    MRT_ACCEL_TILE_CULL = 1,
+    /* The brute-force per-pixel funnel preceded by one test per 4x4 pixel block. */
+    MRT_ACCEL_BLOCK_REJECT = 2
+};
+
+typedef struct mrt_accel_config {
+    int32_t device;       /* HIP device ordinal; -1 = current device            */
+    uint32_t method;      /* MRT_ACCEL_*                                        */
+    uint32_t flags;       /* MRT_FLAG_COUNT_EXACT or 0                          */
+} mrt_accel_config;
+
+typedef struct mrt_accel_stats {
+    mrt_stats frame;      /* as for mrt_ctx frames; frame.kernel says what ran  */
+    double build_ms;      /* GRID: device time of the last build (per view)     */
+    uint64_t cells;       /* GRID: cells of the grid                            */
+    uint64_t refs;        /* GRID: (cell, object) references in all lists       */
+} mrt_accel_stats;
+
+typedef struct mrt_accel mrt_accel;
+
+int mrt_accel_create(const mrt_accel_config *cfg, mrt_accel **out);
+void mrt_accel_destroy(mrt_accel *a);
+/* Text of the last error on a (of the last failed mrt_accel_create when a is NULL). */
+const char *mrt_accel_last_error(const mrt_accel *a);
+uint32_t mrt_accel_method(const mrt_accel *a);
+/* As mrt_set_scene / mrt_set_camera; GRID also (re)builds the grid for the view
+ * and fails with MRT_ERR_TOO_LARGE beyond 2^28 references. */
+int mrt_accel_set_scene(mrt_accel *a, const mrt_scene *scene);
+int mrt_accel_set_camera(mrt_accel *a, const mrt_camera *camera);
+/* As mrt_render_rgba8 / mrt_render_debug / mrt_render_bands_device.  Interleaved
+ * bands (world > 1) must be a multiple of 32 rows for GRID; TILE_CULL and
+ * BLOCK_REJECT fall back to the plain per-pixel kernel for band heights they
+ * cannot tile (32 and 4 rows) and say so in stats->frame.kernel. */
+int mrt_accel_render_rgba8(mrt_accel *a, uint8_t *host_out, mrt_accel_stats *stats /* may be NULL */);
+int mrt_accel_render_debug(mrt_accel *a, uint8_t *host_out, int32_t *ids, float *t, mrt_accel_stats *stats);
+int mrt_accel_render_bands_device(mrt_accel *a, uint32_t band_rows, uint32_t rank, uint32_t world,
+                                  void *dev_out, size_t dev_out_bytes, void *hip_stream,
+                                  mrt_accel_stats *stats);
 
 /* ------------------------------------------------------------------------
  * Scene files.  Same schema, validation order and error strings as the

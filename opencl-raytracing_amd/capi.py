@@ -18,12 +18,13 @@ PKG_DIR = Path(__file__).resolve().parent
 FLAG_NONE = 0
 FLAG_NO_PREFILTER = 1 << 0
 FLAG_COUNT_EXACT = 1 << 1
-FLAG_BLOCK_REJECT = 1 << 2
 FLAG_NO_CIRCLE = 1 << 3
-FLAG_SCREEN_CULL = 1 << 4
 FLAG_FULL_TEST = 1 << 5
-KERNEL_TRACE, KERNEL_TRACE_BLOCK, KERNEL_CULL, KERNEL_FULL = 0, 1, 2, 3    # mrt_stats.kernel
-ABI_VERSION = 2
+RESERVED_FLAG_BITS = (1 << 2) | (1 << 4)          # mrt_create refuses them
+KERNEL_TRACE, KERNEL_TRACE_BLOCK, KERNEL_CULL, KERNEL_FULL, KERNEL_GRID = 0, 1, 2, 3, 4    # mrt_stats.kernel
+ACCEL_GRID, ACCEL_TILE_CULL, ACCEL_BLOCK_REJECT = 0, 1, 2                                 # mrt_accel_config.method
+ACCEL_METHODS = {"grid": ACCEL_GRID, "cull": ACCEL_TILE_CULL, "block": ACCEL_BLOCK_REJECT}
+ABI_VERSION = 3
 PROJ_ORTHO, PROJ_PERSP = 0, 1
 SHADER_FLAT, SHADER_PHONG = 0, 1
 
@@ -38,6 +39,8 @@ EXPORTED_SYMBOLS = [
     "mrt_render_bands_device_noalloc",
     "mrt_multi_create", "mrt_multi_destroy", "mrt_multi_last_error", "mrt_multi_world", "mrt_multi_gather",
     "mrt_multi_note", "mrt_multi_set_scene", "mrt_multi_set_camera", "mrt_multi_render_rgba8",
+    "mrt_accel_create", "mrt_accel_destroy", "mrt_accel_last_error", "mrt_accel_method", "mrt_accel_set_scene",
+    "mrt_accel_set_camera", "mrt_accel_render_rgba8", "mrt_accel_render_debug", "mrt_accel_render_bands_device",
 ]
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST = 0, 1, 2, 3
 NOALLOC_MAX_KEYS = 8 * 1024 * 1024
@@ -87,6 +90,27 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class AccelConfigStruct(C.Structure):
+    """mrt_accel_config."""
+    _fields_ = [("device", C.c_int32), ("method", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class AccelStats(C.Structure):
+    """mrt_accel_stats; the fields of the embedded mrt_stats read through (stats.kernel, stats.trace_ms, ...)."""
+    _fields_ = [("frame", Stats), ("build_ms", C.c_double), ("cells", C.c_uint64), ("refs", C.c_uint64)]
+
+    def __getattr__(self, name):
+        frame = C.Structure.__getattribute__(self, "frame")
+        if name in {f for f, _ in Stats._fields_}:
+            return getattr(frame, name)
+        raise AttributeError(name)
+
+    def as_dict(self):
+        d = self.frame.as_dict()
+        d.update(build_ms=self.build_ms, cells=self.cells, refs=self.refs)
+        return d
 
 
 class MultiConfigStruct(C.Structure):
@@ -205,6 +229,19 @@ def lib():
     L.mrt_multi_set_scene.argtypes = [vp, C.POINTER(SceneStruct)]
     L.mrt_multi_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
     L.mrt_multi_render_rgba8.argtypes = [vp, vp, C.POINTER(MultiStats)]
+    L.mrt_accel_create.argtypes = [C.POINTER(AccelConfigStruct), C.POINTER(vp)]
+    L.mrt_accel_destroy.argtypes = [vp]
+    L.mrt_accel_destroy.restype = None
+    L.mrt_accel_last_error.argtypes = [vp]
+    L.mrt_accel_last_error.restype = C.c_char_p
+    L.mrt_accel_method.argtypes = [vp]
+    L.mrt_accel_method.restype = C.c_uint32
+    L.mrt_accel_set_scene.argtypes = [vp, C.POINTER(SceneStruct)]
+    L.mrt_accel_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
+    L.mrt_accel_render_rgba8.argtypes = [vp, vp, C.POINTER(AccelStats)]
+    L.mrt_accel_render_debug.argtypes = [vp, vp, vp, vp, C.POINTER(AccelStats)]
+    L.mrt_accel_render_bands_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp,
+                                                C.POINTER(AccelStats)]
     L.mrt_bands_to_image.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.mrt_scene_load_file.argtypes = [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.mrt_scene_load_text.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp), C.c_char_p, C.c_size_t]
@@ -441,6 +478,82 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def _camera_of(st):
+    cam = CameraStruct()
+    for name in ("eye", "u", "v", "w", "xres", "yres", "left", "right", "top", "bottom", "projection", "focal"):
+        setattr(cam, name, getattr(st, name))
+    return cam
+
+
+class Accel:
+    """mrt_accel: the same frames as a Context without testing every pair.  Same methods as Context
+    (set_scene, set_camera, render, render_bands_device); stats are AccelStats."""
+
+    def __init__(self, device=-1, method=ACCEL_GRID, flags=FLAG_NONE):
+        L = lib()
+        self._h = C.c_void_p()
+        cfg = AccelConfigStruct(device, ACCEL_METHODS.get(method, method), flags)
+        rc = L.mrt_accel_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise MrtError(rc, L.mrt_accel_last_error(None).decode())
+        self.method = L.mrt_accel_method(self._h)
+        self.xres = self.yres = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MrtError(rc, lib().mrt_accel_last_error(self._h).decode())
+
+    def set_scene(self, scene):
+        st = scene.struct
+        self._check(lib().mrt_accel_set_scene(self._h, C.byref(st)))
+        self.xres, self.yres = st.xres, st.yres
+
+    def set_camera(self, scene):
+        st = scene.struct
+        cam = _camera_of(st)
+        self._check(lib().mrt_accel_set_camera(self._h, C.byref(cam)))
+        self.xres, self.yres = st.xres, st.yres
+
+    def render(self, want_ids=False, out=None):
+        stats = AccelStats()
+        img = np.empty((self.yres, self.xres, 4), np.uint8) if out is None else out
+        if img.shape != (self.yres, self.xres, 4) or img.dtype != np.uint8 or not img.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of shape (yres, xres, 4)")
+        if not want_ids:
+            self._check(lib().mrt_accel_render_rgba8(self._h, img.ctypes.data, C.byref(stats)))
+            return img, stats
+        ids = np.empty((self.yres, self.xres), np.int32)
+        t = np.empty((self.yres, self.xres), np.float32)
+        self._check(lib().mrt_accel_render_debug(self._h, img.ctypes.data, ids.ctypes.data, t.ctypes.data,
+                                                 C.byref(stats)))
+        return img, ids, t, stats
+
+    def render_bands_device(self, band_rows_, rank, world, dev_ptr, nbytes, stream=0, timed=False):
+        stats = AccelStats() if timed else None
+        self._check(lib().mrt_accel_render_bands_device(self._h, band_rows_, rank, world, dev_ptr, nbytes,
+                                                        stream or None, C.byref(stats) if timed else None))
+        return stats
+
+    def close(self):
+        if self._h:
+            lib().mrt_accel_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def renderer(device=-1, kind=0, flags=FLAG_NONE):
+    """A brute-force Context for an integer flag set, an Accel for a method name ("grid", "cull",
+    "block"): the two families render the same frames and share their Python methods."""
+    if isinstance(kind, str):
+        return Accel(device=device, method=kind, flags=flags)
+    return Context(device=device, flags=int(kind) | flags)
 
 
 class MultiContext:

@@ -8,6 +8,7 @@
 // records on the GPU (mrt_set_camera, no copies, no waiting) and a frame is one
 // or two kernel launches.
 #include "mrt.h"
+#include "mrt_internal.hpp"
 #include "mrt_kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -288,16 +289,16 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     // image rows whatever its height; only interleaved bands constrain the block kernels.
     const bool consecutive = world == 1 || band_rows >= p.yres;
     // The block reject needs a lane's four rows to be consecutive image rows.
-    const bool block = (ctx->flags & MRT_FLAG_BLOCK_REJECT) && (consecutive || band_rows % 4 == 0);
+    const bool block = (ctx->flags & MRT_IFLAG_BLOCK_REJECT) && (consecutive || band_rows % 4 == 0);
     const bool persp = ctx->projection == MRT_PROJ_PERSP;
     const dim3 tb(mrt::kBlockThreads);
     // The tile cull needs a wave tile's 32 rows to be consecutive image rows, and it has no
     // exact-only mode of its own.
     const bool full = (ctx->flags & MRT_FLAG_FULL_TEST) != 0;
-    const bool cull = !full && (ctx->flags & MRT_FLAG_SCREEN_CULL) && !(ctx->flags & MRT_FLAG_NO_PREFILTER) &&
+    const bool cull = !full && (ctx->flags & MRT_IFLAG_SCREEN_CULL) && !(ctx->flags & MRT_FLAG_NO_PREFILTER) &&
                       (consecutive || band_rows % mrt::kWaveTile == 0);
     if (cull && !planes.own)
-        return fail(ctx, MRT_ERR_INVALID, "MRT_FLAG_SCREEN_CULL needs per-pixel planes of its own; not available without allocation");
+        return fail(ctx, MRT_ERR_INVALID, "the tile-cull kernel needs per-pixel planes of its own; not available without allocation");
 
     // Working planes.  trace_kernel keeps the closest hit of every pixel in a 64-bit key plane;
     // the tile cull hands (t, id) planes to shade_kernel; full_trace_kernel needs neither.
@@ -461,6 +462,10 @@ int fill_stats(mrt_ctx* ctx, mrt_stats* st, uint32_t rows) {
 // Shared with mrt_stages.hip (not part of the public ABI).
 extern "C" int mrt_stage_set_error_(mrt_ctx* ctx, int code, const char* msg) { return fail(ctx, code, msg ? msg : ""); }
 extern "C" int mrt_stage_device_(const mrt_ctx* ctx) { return ctx ? ctx->device : 0; }
+// Shared with mrt_accel.hip (mrt_internal.hpp).
+extern "C" const mrt::RenderParams* mrt_ctx_params_(const mrt_ctx* ctx) { return &ctx->params; }
+extern "C" void* mrt_ctx_stream_(const mrt_ctx* ctx) { return (void*)ctx->stream; }
+extern "C" int mrt_ctx_projection_(const mrt_ctx* ctx) { return ctx->projection; }
 
 extern "C" {
 
@@ -469,6 +474,15 @@ int mrt_abi_version(void) { return MRT_ABI_VERSION; }
 const char* mrt_last_error(const mrt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int mrt_create(const mrt_config* cfg, mrt_ctx** out) {
+    if (!out) return fail(nullptr, MRT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (cfg && (cfg->flags & MRT_IFLAG_MASK))
+        return fail(nullptr, MRT_ERR_INVALID,
+                    "flag bits 2 and 4 are reserved: screen-space culling is behind mrt_accel_create, not a flag of the brute-force context");
+    return mrt_create_internal_(cfg, out);
+}
+
+int mrt_create_internal_(const mrt_config* cfg, mrt_ctx** out) {
     if (!out) return fail(nullptr, MRT_ERR_INVALID, "out is NULL");
     *out = nullptr;
     int count = 0;

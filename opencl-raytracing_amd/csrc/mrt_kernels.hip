@@ -24,11 +24,14 @@
 //                      winner are those of the reference loop.
 //   full_trace_kernel  MRT_FLAG_FULL_TEST: a general-ray 3x3 solve (fused) for
 //                      every pair, the reference arithmetic for the survivors.
-//   cull_trace_kernel  MRT_FLAG_SCREEN_CULL (opt-in): lanes first test 64
-//                      primitives each against the whole wave tile.
+//   cull_trace_kernel  not a brute-force kernel (mrt_accel_*): lanes first test
+//                      64 primitives each against the whole wave tile.
+//   grid_trace_kernel  not a brute-force kernel either (mrt_accel_*): walks the
+//                      per-tile primitive lists of a grid built per view.
 #include "mrt.h"
 #include "mrt_device.hpp"
 #include "mrt_kernels.hpp"
+#include "mrt_tile_tests.hpp"
 
 #include <float.h>
 #include <type_traits>
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
         for (int g = gc; g < gc + kGroupCircle; g += kGroupTris) {
             if (base + g >= p.n_tri) break;
             if (BLOCK_REJECT) {
-                // Opt-in (MRT_FLAG_BLOCK_REJECT): each edge function is monotone in x and
+                // mrt_accel_* only (method MRT_ACCEL_BLOCK_REJECT): each edge function is monotone in x and
                 // in y, so its maximum over this lane's 4x4 block is its value at one
                 // corner; the record carries C'_k = C_k + 3*max(A_k,0) + 3*max(B_k,0), which
                 // moves that corner to the block origin.  If some edge is negative at its
@@ -526,8 +529,226 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     }
 }
 
+namespace {
+
+// What a wave that owns a whole 32x32 pixel tile keeps for it (tile-cull and grid kernels): the
+// closest hit of the tile's 1024 pixels in LDS as 64-bit (t, id) keys, a pixel list for the exact
+// step, and the uv components of its columns and rows.  All of it belongs to this wave alone.
+struct TileState {
+    unsigned long long* keys;      // [32 * 32]
+    uint16_t* list;                // [32 * 32]
+    uint32_t* count;               // fill of the list
+    float* tile_ux;                // [32]
+    float* tile_uy;                // [32]
+    uint32_t bx, by;               // this lane's 4x4 block inside the tile
+    float xf, yf0;                 // ... and its first pixel in image coordinates
+    int lane;
+};
+
+// One sphere that may touch the tile: its ellipse record f per pixel of the lane's 4x4 block,
+// then the reference arithmetic over the pixels that pass.
+template <int PROJ>
+__device__ __forceinline__ void survivor_sphere(const RenderParams& p, uint32_t si, float4 f, const TileState& st,
+                                                unsigned long long& n_exact, bool& recorded) {
+    // wave-uniform loads land in scalar registers; VALU operands read from those issue at half rate
+    const float fx = in_vgpr(f.x), fz = in_vgpr(f.z);
+    uint32_t mask = 0;
+    float dup = __builtin_fmaf(st.xf, fx, f.y);
+#pragma unroll
+    for (int i = 0; i < kLanePx; ++i) {
+#pragma unroll
+        for (int j = 0; j < kLanePx; ++j) {
+            const float dvp = __builtin_fmaf(st.yf0 + (float)j, fz, f.w);
+            if (__builtin_fmaf(dup, dup, __builtin_fmaf(dvp, dvp, -1.0f)) <= 0.0f) mask |= 1u << (j * kLanePx + i);
+        }
+        dup += fx;
+    }
+    if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) return;
+    const uint32_t total = list_pixels(mask, st.bx, st.by, st.lane, st.list, st.count);
+    exact_list<PROJ, false>(p, si, total, st.lane, st.list, st.tile_ux, st.tile_uy, st.keys, kWaveTile, n_exact, recorded);
+}
+
+// One triangle that may touch the tile, record (q0, q1, q2): 4x4 block reject at the best corner
+// of the lane's block (via C'_k, see store_record in mrt_records.hip), the three edge functions
+// per pixel, then the reference arithmetic over the pixels that pass.
+template <int PROJ>
+__device__ __forceinline__ void survivor_triangle(const RenderParams& p, uint32_t ti, float4 q0, float4 q1, float4 q2,
+                                                  const TileState& st, unsigned long long& n_exact, bool& recorded) {
+    const float a0 = in_vgpr(q0.x), b0 = in_vgpr(q0.y), a1 = in_vgpr(q0.w), b1 = in_vgpr(q1.x),
+                a2 = in_vgpr(q1.z), b2 = in_vgpr(q1.w);
+    const float m0 = __builtin_fmaf(a0, st.xf, __builtin_fmaf(b0, st.yf0, q2.y));
+    const float m1 = __builtin_fmaf(a1, st.xf, __builtin_fmaf(b1, st.yf0, q2.z));
+    const float m2 = __builtin_fmaf(a2, st.xf, __builtin_fmaf(b2, st.yf0, q2.w));
+    const bool blk = __builtin_fminf(__builtin_fminf(m0, m1), m2) >= 0.0f;
+    if (__builtin_amdgcn_ballot_w64(blk) == 0) return;
+    const float c0 = __builtin_fmaf(a0, st.xf, q0.z);
+    const float c1 = __builtin_fmaf(a1, st.xf, q1.y);
+    const float c2 = __builtin_fmaf(a2, st.xf, q2.x);
+    uint32_t mask = 0;
+#pragma unroll
+    for (int j = 0; j < kLanePx; ++j) {
+        const float y = st.yf0 + (float)j;
+        float v0 = __builtin_fmaf(b0, y, c0);
+        float v1 = __builtin_fmaf(b1, y, c1);
+        float v2 = __builtin_fmaf(b2, y, c2);
+#pragma unroll
+        for (int i = 0; i < kLanePx; ++i) {
+            if (__builtin_fminf(__builtin_fminf(v0, v1), v2) >= 0.0f) mask |= 1u << (j * kLanePx + i);
+            v0 += a0; v1 += a1; v2 += a2;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) return;
+    const uint32_t total = list_pixels(mask, st.bx, st.by, st.lane, st.list, st.count);
+    exact_list<PROJ, true>(p, ti, total, st.lane, st.list, st.tile_ux, st.tile_uy, st.keys, kWaveTile, n_exact, recorded);
+}
+
+// Fills the tile's uv tables (gfxraytrace.hpp:850-852: the pixel grid is (x + 1, y + 1); rows
+// past the end of this rank's rows repeat the last one, as everywhere), sets every key to
+// "no hit" and empties the list.  LDS operations of one wave complete in order and no other wave
+// touches these arrays, so a wave-level fence is all the synchronisation they need.
+__device__ __forceinline__ void tile_begin(const RenderParams& p, const TileState& st, uint32_t wave_x0, uint32_t wave_lr0) {
+    const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
+    const uint32_t k = st.lane & 31;
+    if (st.lane < 32) {
+        st.tile_ux[k] = uv_component(p.left, p.right, (float)(wave_x0 + k) + 1.0f, p.xres_f);
+    } else {
+        const uint32_t lr = wave_lr0 + k;
+        st.tile_uy[k] = uv_component(p.bottom, p.top, (float)image_row(p, lr < last_row ? lr : last_row) + 1.0f, p.yres_f);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < kWaveTile * kWaveTile / 64; ++k2) st.keys[k2 * 64 + st.lane] = kNoHitKey;
+    if (st.lane == 0) *st.count = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The lane's 4x4 block of closest hits out of the tile's keys: (t, id) planes when asked for
+// (t_out != nullptr), shaded RGBA8 when SHADE (and p.fuse_shade) is set.
+template <int PROJ, bool SHADE>
+__device__ __forceinline__ void tile_end(const RenderParams& p, const TileState& st, uint32_t x0, uint32_t lr0,
+                                         float* __restrict__ t_out, int32_t* __restrict__ id_out, uint32_t pitch) {
+    // The atomics are complete before this wave reads the keys back.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < kLanePx; ++j) {
+        unsigned long long k4[kLanePx];
+#pragma unroll
+        for (int i = 0; i < kLanePx; ++i) k4[i] = st.keys[(st.by + j) * kWaveTile + st.bx + i];
+        int4 iv;
+        float4 tv;
+        iv.x = (int32_t)(uint32_t)k4[0]; iv.y = (int32_t)(uint32_t)k4[1];
+        iv.z = (int32_t)(uint32_t)k4[2]; iv.w = (int32_t)(uint32_t)k4[3];
+        tv.x = iv.x < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[0] >> 32));      // intersect.t_ of a miss, kernel.cl:363
+        tv.y = iv.y < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[1] >> 32));
+        tv.z = iv.z < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[2] >> 32));
+        tv.w = iv.w < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[3] >> 32));
+        if (t_out != nullptr) {
+            const size_t off = (size_t)(lr0 + j) * pitch + x0;
+            *reinterpret_cast<float4*>(t_out + off) = tv;
+            *reinterpret_cast<int4*>(id_out + off) = iv;
+        }
+        if (SHADE && p.fuse_shade) shade_row4<PROJ>(p, x0, lr0 + j, tv, iv);
+    }
+}
+
+// Four RGBA8 pixels of local row lr starting at column x0 (a multiple of 4): one aligned 16-byte
+// store when p.fuse_shade == 2, single pixels inside the image otherwise.
+__device__ __forceinline__ void store_row4(const RenderParams& p, uint32_t x0, uint32_t lr, const uint32_t px[4]) {
+    if (!(lr < p.local_rows && x0 < p.xres)) return;
+    uint32_t* dst = p.out + (size_t)lr * p.xres + x0;
+    if (p.fuse_shade == 2) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (x0 + i < p.xres) dst[i] = px[i];
+    }
+}
+
+// A tile nothing hit: background bytes for the lane's 4x4 block, "miss" in the planes if asked.
+__device__ __forceinline__ void tile_background(const RenderParams& p, uint32_t bg, uint32_t x0, uint32_t lr0,
+                                                float* __restrict__ t_out, int32_t* __restrict__ id_out, uint32_t pitch) {
+    const uint32_t px[4] = {bg, bg, bg, bg};
+#pragma unroll
+    for (int j = 0; j < kLanePx; ++j) {
+        if (t_out != nullptr) {
+            const size_t off = (size_t)(lr0 + j) * pitch + x0;
+            *reinterpret_cast<float4*>(t_out + off) = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);     // kernel.cl:363
+            *reinterpret_cast<int4*>(id_out + off) = make_int4(-1, -1, -1, -1);
+        }
+        store_row4(p, x0, lr0 + j, px);
+    }
+}
+
+// The end of a tile whose wave shades it: the pixels that were hit are listed (list_pixels) and
+// shaded 64 at a time by whichever lane is free -- Blinn-Phong is several hundred dependent
+// instructions, and a lane that walks its own 4x4 block would drag its 63 neighbours through them
+// for every hit pixel it owns -- with the colour put where the key was (upper word 0: no hit has
+// t == 0).  Then every lane stores its block: the colour where there is one, background elsewhere.
+template <int PROJ>
+__device__ __forceinline__ void tile_end_shaded(const RenderParams& p, const TileState& st, uint32_t bg,
+                                                uint32_t wave_x0, uint32_t wave_lr0, uint32_t x0, uint32_t lr0,
+                                                float* __restrict__ t_out, int32_t* __restrict__ id_out, uint32_t pitch) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t mask = 0;
+#pragma unroll
+    for (int j = 0; j < kLanePx; ++j) {
+        int4 iv;
+        float4 tv;
+        int32_t ids[kLanePx];
+        float ts[kLanePx];
+#pragma unroll
+        for (int i = 0; i < kLanePx; ++i) {
+            const unsigned long long k = st.keys[(st.by + j) * kWaveTile + st.bx + i];
+            ids[i] = (int32_t)(uint32_t)k;
+            ts[i] = ids[i] < 0 ? -1.0f : __uint_as_float((uint32_t)(k >> 32));       // intersect.t_ of a miss, kernel.cl:363
+            if (ids[i] >= 0 && x0 + i < p.xres && lr0 + j < p.local_rows) mask |= 1u << (j * kLanePx + i);
+        }
+        if (t_out != nullptr) {
+            iv.x = ids[0]; iv.y = ids[1]; iv.z = ids[2]; iv.w = ids[3];
+            tv.x = ts[0]; tv.y = ts[1]; tv.z = ts[2]; tv.w = ts[3];
+            const size_t off = (size_t)(lr0 + j) * pitch + x0;
+            *reinterpret_cast<float4*>(t_out + off) = tv;
+            *reinterpret_cast<int4*>(id_out + off) = iv;
+        }
+    }
+    const uint32_t total = list_pixels(mask, st.bx, st.by, st.lane, st.list, st.count);
+    for (uint32_t b = 0; b < total; b += 64) {
+        const uint32_t idx = b + (uint32_t)st.lane;
+        if (idx < total) {
+            const uint32_t px = st.list[idx];
+            const unsigned long long k = st.keys[px];
+            const uint32_t x = wave_x0 + (px & 31u), lr = wave_lr0 + (px >> 5);
+            const uint32_t c = shade_pixel<PROJ>(p, x, image_row(p, lr), __uint_as_float((uint32_t)(k >> 32)),
+                                                 (int32_t)(uint32_t)k);
+            st.keys[px] = (unsigned long long)c;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < kLanePx; ++j) {
+        uint32_t px[kLanePx];
+#pragma unroll
+        for (int i = 0; i < kLanePx; ++i) {
+            const unsigned long long k = st.keys[(st.by + j) * kWaveTile + st.bx + i];
+            px[i] = (uint32_t)(k >> 32) == 0u ? (uint32_t)k : bg;
+        }
+        store_row4(p, x0, lr0 + j, px);
+    }
+}
+
+}  // namespace
+
 // ---------------------------------------------------------------------------
-// Opt-in screen-space culling (MRT_FLAG_SCREEN_CULL); never the default path.
+// Screen-space tile culling (mrt_accel_*, method MRT_ACCEL_TILE_CULL); never the
+// brute-force path.
 //
 // Same tiles and records as trace_kernel, but the first rejection is done per
 // wave tile with the lanes spread over PRIMITIVES: lane l tests primitive
@@ -563,73 +784,31 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
     const uint32_t wave_x0 = blockIdx.x * kBlockTileX + (wave & 1) * kWaveTile;
     const uint32_t wave_lr0 = blockIdx.y * kBlockTileY + (wave >> 1) * kWaveTile;
     if (!((wave_x0 < p.xres) && (wave_lr0 < p.local_rows))) return;   // no block-level barriers in this kernel
-    const uint32_t bx = (lane & 7) * kLanePx, by = (lane >> 3) * kLanePx;   // this lane's block inside the tile
-    const uint32_t x0 = wave_x0 + bx;
-    const uint32_t lr0 = wave_lr0 + by;
-    unsigned long long* keys = s_key[wave];
-    uint16_t* list = s_list[wave];
-    float* tile_ux = s_ux[wave];
-    float* tile_uy = s_uy[wave];
-
+    TileState st;
+    st.keys = s_key[wave]; st.list = s_list[wave]; st.count = &s_count[wave];
+    st.tile_ux = s_ux[wave]; st.tile_uy = s_uy[wave];
+    st.bx = (lane & 7) * kLanePx; st.by = (lane >> 3) * kLanePx;     // this lane's block inside the tile
+    st.lane = lane;
+    const uint32_t x0 = wave_x0 + st.bx;
+    const uint32_t lr0 = wave_lr0 + st.by;
     // Tile and lane-block origins in image pixel coordinates.
     const float txf = (float)wave_x0;
     const float tyf = (float)image_row(p, wave_lr0);
-    const float xf = (float)x0;
-    const float yf0 = tyf + (float)by;
-    const float tile_span = (float)(kWaveTile - 1);
-
-    // uv of the tile's 32 columns and 32 rows (gfxraytrace.hpp:850-852: the pixel grid is
-    // (x + 1, y + 1)); rows past the end of this rank's rows repeat the last one, as everywhere.
-    {
-        const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
-        const uint32_t k = lane & 31;
-        if (lane < 32) {
-            tile_ux[k] = uv_component(p.left, p.right, (float)(wave_x0 + k) + 1.0f, p.xres_f);
-        } else {
-            const uint32_t lr = wave_lr0 + k;
-            tile_uy[k] = uv_component(p.bottom, p.top, (float)image_row(p, lr < last_row ? lr : last_row) + 1.0f, p.yres_f);
-        }
-#pragma unroll
-        for (int k2 = 0; k2 < kTilePx / 64; ++k2) keys[k2 * 64 + lane] = kNoHitKey;
-        if (lane == 0) s_count[wave] = 0;
-    }
-    // LDS operations of one wave complete in order and no other wave touches these arrays, so
-    // a wave-level fence is all the synchronisation this kernel needs.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    st.xf = (float)x0;
+    st.yf0 = tyf + (float)st.by;
+    tile_begin(p, st, wave_x0, wave_lr0);
     unsigned long long n_exact = 0;
     bool recorded = false;
 
     // ---- spheres ----
     for (uint32_t base = 0; base < p.n_sph; base += 64) {
         const float4 e = p.sph_filter[base + lane];          // padded to a multiple of 768
-        // (x*sx + ox) is monotone in x: nearest-to-zero value over the tile's columns.
-        const float du_lo = __builtin_fmaf(txf, e.x, e.y), dv_lo = __builtin_fmaf(tyf, e.z, e.w);
-        const float du = __builtin_amdgcn_fmed3f(du_lo, __builtin_fmaf(tile_span, e.x, du_lo), 0.0f);
-        const float dv = __builtin_amdgcn_fmed3f(dv_lo, __builtin_fmaf(tile_span, e.z, dv_lo), 0.0f);
-        // 1e-6: the per-pixel evaluation below rounds differently from this one.
-        const bool pass = (__builtin_fmaf(du, du, dv * dv) <= 1.000001f) && (base + lane < p.n_sph);
+        const bool pass = tile_may_hit_sphere(e, txf, tyf) && (base + lane < p.n_sph);
         unsigned long long live = __builtin_amdgcn_ballot_w64(pass);
         while (live) {
             const uint32_t si = base + (uint32_t)__builtin_ctzll(live);
             live &= live - 1;
-            const float4 f = p.sph_filter[si];
-            const float fx = in_vgpr(f.x), fz = in_vgpr(f.z);
-            uint32_t mask = 0;
-            float dup = __builtin_fmaf(xf, fx, f.y);
-#pragma unroll
-            for (int i = 0; i < kLanePx; ++i) {
-#pragma unroll
-                for (int j = 0; j < kLanePx; ++j) {
-                    const float dvp = __builtin_fmaf(yf0 + (float)j, fz, f.w);
-                    if (__builtin_fmaf(dup, dup, __builtin_fmaf(dvp, dvp, -1.0f)) <= 0.0f) mask |= 1u << (j * kLanePx + i);
-                }
-                dup += fx;
-            }
-            if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
-            const uint32_t total = list_pixels(mask, bx, by, lane, list, &s_count[wave]);
-            exact_list<PROJ, false>(p, si, total, lane, list, tile_ux, tile_uy, keys, kWaveTile, n_exact, recorded);
+            survivor_sphere<PROJ>(p, si, p.sph_filter[si], st, n_exact, recorded);
         }
     }
 
@@ -637,83 +816,127 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
     for (uint32_t base = 0; base < p.n_tri; base += 64) {
         const uint32_t mine = base + lane;                    // records are padded to a multiple of 256
         const float4 c = p.tri_circle[mine];
-        const float cu = __builtin_amdgcn_fmed3f(txf - c.x, txf + tile_span - c.x, 0.0f);
-        const float cv = __builtin_amdgcn_fmed3f(tyf - c.y, tyf + tile_span - c.y, 0.0f);
-        bool pass = __builtin_fmaf(cu, cu, __builtin_fmaf(cv, cv, -c.z)) <= 0.0f;
-        if (pass) {
-            // each edge function at the tile corner where it is largest
-            const float4 q0 = p.tri_filter[(size_t)mine * 3 + 0];
-            const float4 q1 = p.tri_filter[(size_t)mine * 3 + 1];
-            const float4 q2 = p.tri_filter[(size_t)mine * 3 + 2];
-            const float a[3] = {q0.x, q0.w, q1.z}, b[3] = {q0.y, q1.x, q1.w}, cc[3] = {q0.z, q1.y, q2.x};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float best_x = a[k] > 0.0f ? txf + tile_span : txf;
-                const float best_y = b[k] > 0.0f ? tyf + tile_span : tyf;
-                // slack 1e-3 px for the different rounding of the per-pixel evaluation
-                pass = pass && (__builtin_fmaf(a[k], best_x, __builtin_fmaf(b[k], best_y, cc[k])) >= -1e-3f);
-            }
-        }
+        const bool pass = tile_may_hit_triangle(c, p.tri_filter + (size_t)mine * 3, txf, tyf);
         unsigned long long live = __builtin_amdgcn_ballot_w64(pass && mine < p.n_tri);
         while (live) {
             const uint32_t ti = base + (uint32_t)__builtin_ctzll(live);
             live &= live - 1;
-            const float4 q0 = p.tri_filter[(size_t)ti * 3 + 0];
-            const float4 q1 = p.tri_filter[(size_t)ti * 3 + 1];
-            const float4 q2 = p.tri_filter[(size_t)ti * 3 + 2];
-            // wave-uniform loads land in scalar registers; VALU operands read from those issue at half rate
-            const float a0 = in_vgpr(q0.x), b0 = in_vgpr(q0.y), a1 = in_vgpr(q0.w), b1 = in_vgpr(q1.x),
-                        a2 = in_vgpr(q1.z), b2 = in_vgpr(q1.w);
-            // 4x4 block reject: best corner of this lane's block, via C'_k (see push_record)
-            const float m0 = __builtin_fmaf(a0, xf, __builtin_fmaf(b0, yf0, q2.y));
-            const float m1 = __builtin_fmaf(a1, xf, __builtin_fmaf(b1, yf0, q2.z));
-            const float m2 = __builtin_fmaf(a2, xf, __builtin_fmaf(b2, yf0, q2.w));
-            const bool blk = __builtin_fminf(__builtin_fminf(m0, m1), m2) >= 0.0f;
-            if (__builtin_amdgcn_ballot_w64(blk) == 0) continue;
-            const float c0 = __builtin_fmaf(a0, xf, q0.z);
-            const float c1 = __builtin_fmaf(a1, xf, q1.y);
-            const float c2 = __builtin_fmaf(a2, xf, q2.x);
-            uint32_t mask = 0;
-#pragma unroll
-            for (int j = 0; j < kLanePx; ++j) {
-                const float y = yf0 + (float)j;
-                float v0 = __builtin_fmaf(b0, y, c0);
-                float v1 = __builtin_fmaf(b1, y, c1);
-                float v2 = __builtin_fmaf(b2, y, c2);
-#pragma unroll
-                for (int i = 0; i < kLanePx; ++i) {
-                    if (__builtin_fminf(__builtin_fminf(v0, v1), v2) >= 0.0f) mask |= 1u << (j * kLanePx + i);
-                    v0 += a0; v1 += a1; v2 += a2;
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
-            const uint32_t total = list_pixels(mask, bx, by, lane, list, &s_count[wave]);
-            exact_list<PROJ, true>(p, ti, total, lane, list, tile_ux, tile_uy, keys, kWaveTile, n_exact, recorded);
+            survivor_triangle<PROJ>(p, ti, p.tri_filter[(size_t)ti * 3 + 0], p.tri_filter[(size_t)ti * 3 + 1],
+                                    p.tri_filter[(size_t)ti * 3 + 2], st, n_exact, recorded);
         }
     }
 
-    // The atomics above are complete before this wave reads the keys back.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int j = 0; j < kLanePx; ++j) {
-        const size_t off = (size_t)(lr0 + j) * pitch + x0;
-        unsigned long long k4[kLanePx];
-#pragma unroll
-        for (int i = 0; i < kLanePx; ++i) k4[i] = keys[(by + j) * kWaveTile + bx + i];
-        int4 iv;
-        float4 tv;
-        iv.x = (int32_t)(uint32_t)k4[0]; iv.y = (int32_t)(uint32_t)k4[1];
-        iv.z = (int32_t)(uint32_t)k4[2]; iv.w = (int32_t)(uint32_t)k4[3];
-        tv.x = iv.x < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[0] >> 32));      // intersect.t_ of a miss, kernel.cl:363
-        tv.y = iv.y < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[1] >> 32));
-        tv.z = iv.z < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[2] >> 32));
-        tv.w = iv.w < 0 ? -1.0f : __uint_as_float((uint32_t)(k4[3] >> 32));
-        *reinterpret_cast<float4*>(t_out + off) = tv;
-        *reinterpret_cast<int4*>(id_out + off) = iv;       // shade_kernel takes it from here
-    }
+    tile_end<PROJ, false>(p, st, x0, lr0, t_out, id_out, pitch);       // shade_kernel takes the planes from here
     if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
+}
+
+// ---------------------------------------------------------------------------
+// Screen-space uniform grid (mrt_accel_*, method MRT_ACCEL_GRID); never the
+// brute-force path.
+//
+// The cells of the grid are the 32x32 pixel tiles of the image; per view,
+// mrt_accel.hip bins every primitive into the tiles it may touch (the tile
+// tests of mrt_tile_tests.hpp, run once) and leaves, per tile, a list of object
+// ids: refs[cell_start[c] .. cell_start[c + 1]).  A wave owns a tile exactly as
+// in cull_trace_kernel -- closest hits as (t, id) keys in LDS, survivors tested
+// per 4x4 block and per pixel, the reference arithmetic over the pixels that
+// pass -- but walks only its tile's list.  The prefilter records of a batch of
+// 32 listed objects are fetched by all lanes at once and staged in LDS, so the
+// per-object loop reads them as LDS broadcasts instead of waiting for one
+// scalar load after another.  The order of a list is whatever the binning
+// atomics gave: the keys make the winner independent of it.  The kernel shades
+// its own pixels (no (t, id) planes unless asked for): a cell with an empty list,
+// or one in which nothing was hit, is filled with the background colour; in the
+// others the hit pixels are listed and shaded 64 at a time.  Needs a tile's 32
+// rows to be consecutive image rows starting at a multiple of 32.
+// ---------------------------------------------------------------------------
+constexpr int kGridBatch = 32;
+
+template <int PROJ>
+__global__ __launch_bounds__(kBlockThreads) void grid_trace_kernel(const RenderParams p,
+                                                                  const uint32_t* __restrict__ cell_start,
+                                                                  const uint32_t* __restrict__ refs,
+                                                                  uint32_t grid_tiles_x,
+                                                                  float* __restrict__ t_out,
+                                                                  int32_t* __restrict__ id_out,
+                                                                  uint32_t pitch) {
+    constexpr int kWaves = kBlockThreads / 64, kTilePx = kWaveTile * kWaveTile;
+    __shared__ unsigned long long s_key[kWaves][kTilePx];
+    __shared__ uint16_t s_list[kWaves][kTilePx];
+    __shared__ float4 s_batch[kWaves][kGridBatch * 3];        // records of the objects being walked
+    __shared__ float s_ux[kWaves][kWaveTile], s_uy[kWaves][kWaveTile];
+    __shared__ uint32_t s_count[kWaves];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t wave_x0 = blockIdx.x * kBlockTileX + (wave & 1) * kWaveTile;
+    const uint32_t wave_lr0 = blockIdx.y * kBlockTileY + (wave >> 1) * kWaveTile;
+    if (!((wave_x0 < p.xres) && (wave_lr0 < p.local_rows))) return;   // no block-level barriers in this kernel
+    TileState st;
+    st.keys = s_key[wave]; st.list = s_list[wave]; st.count = &s_count[wave];
+    st.tile_ux = s_ux[wave]; st.tile_uy = s_uy[wave];
+    st.bx = (lane & 7) * kLanePx; st.by = (lane >> 3) * kLanePx;
+    st.lane = lane;
+    const uint32_t x0 = wave_x0 + st.bx;
+    const uint32_t lr0 = wave_lr0 + st.by;
+    const uint32_t tile_row0 = image_row(p, wave_lr0);
+    st.xf = (float)x0;
+    st.yf0 = (float)tile_row0 + (float)st.by;
+    const uint32_t bg = shade_pixel<PROJ>(p, 0u, 0u, -1.0f, -1);       // the colour of a miss
+    const uint32_t cell = (tile_row0 / kWaveTile) * grid_tiles_x + wave_x0 / kWaveTile;
+    const uint32_t begin = cell_start[cell], end = cell_start[cell + 1];
+    if (begin == end) {                // nothing is listed for this cell
+        tile_background(p, bg, x0, lr0, t_out, id_out, pitch);
+        return;
+    }
+    tile_begin(p, st, wave_x0, wave_lr0);
+    unsigned long long n_exact = 0;
+    bool recorded = false;
+    float4* batch = s_batch[wave];
+
+    for (uint32_t base = begin; base < end; base += kGridBatch) {
+        const uint32_t n = (end - base) < (uint32_t)kGridBatch ? (end - base) : (uint32_t)kGridBatch;
+        const uint32_t ref = (uint32_t)lane < n ? refs[base + lane] : 0u;
+        // 96 record slots, two per lane: slot s is part s % 3 of listed object s / 3.  A sphere
+        // has one part (its ellipse), a triangle three (its edge record).
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s = lane + 64 * h;
+            const int k = s / 3, part = s - 3 * k;
+            const uint32_t obj = (uint32_t)__builtin_amdgcn_ds_bpermute(k << 2, (int)ref);
+            if (s < kGridBatch * 3 && (uint32_t)k < n) {
+                if (obj < p.n_sph) {
+                    if (part == 0) batch[s] = p.sph_filter[obj];
+                } else {
+                    batch[s] = p.tri_filter[(size_t)(obj - p.n_sph) * 3 + part];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t obj = (uint32_t)__builtin_amdgcn_readlane((int)ref, (int)k);
+            if (obj < p.n_sph)
+                survivor_sphere<PROJ>(p, obj, batch[k * 3], st, n_exact, recorded);
+            else
+                survivor_triangle<PROJ>(p, obj - p.n_sph, batch[k * 3 + 0], batch[k * 3 + 1], batch[k * 3 + 2], st,
+                                        n_exact, recorded);
+        }
+        // the next batch overwrites the records only after the reads above
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
+    if (!recorded)
+        tile_background(p, bg, x0, lr0, t_out, id_out, pitch);
+    else if (p.fuse_shade)
+        tile_end_shaded<PROJ>(p, st, bg, wave_x0, wave_lr0, x0, lr0, t_out, id_out, pitch);
+    else
+        tile_end<PROJ, false>(p, st, x0, lr0, t_out, id_out, pitch);
 }
 
 // ---------------------------------------------------------------------------
@@ -1166,6 +1389,8 @@ template __global__ void prep_full_records<MRT_PROJ_ORTHO>(const RenderParams, f
 template __global__ void prep_full_records<MRT_PROJ_PERSP>(const RenderParams, float4*, uint32_t*, uint32_t*);
 template __global__ void cull_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, float*, int32_t*, uint32_t);
 template __global__ void cull_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, float*, int32_t*, uint32_t);
+template __global__ void grid_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, const uint32_t*, const uint32_t*, uint32_t, float*, int32_t*, uint32_t);
+template __global__ void grid_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, const uint32_t*, const uint32_t*, uint32_t, float*, int32_t*, uint32_t);
 
 template __global__ void shade_keys_kernel<MRT_PROJ_ORTHO>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void shade_keys_kernel<MRT_PROJ_PERSP>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);

@@ -9,7 +9,9 @@
 //
 // Environment (all optional; the two positional arguments are the whole contract):
 //   MRT_STATS=1        one JSON line with timings on stderr
-//   MRT_FLAGS=<int>    mrt_config.flags: one of the library's other kernels, same pixels
+//   MRT_FLAGS=<int>    mrt_config.flags: one of the library's other brute-force kernels, same pixels
+//   MRT_ACCEL=grid|cull|block   render through mrt_accel_* (screen-space grid, tile cull, block
+//                      reject) instead of the brute-force context: same pixels; one GPU only
 //   MRT_GPUS=<n|all>   render on n GPUs of this node at once (interleaved row bands, mrt_multi_*)
 //   MRT_GPU_LIST=a,b,. the HIP ordinals of the ranks instead of 0 .. n-1; an ordinal may repeat
 //   MRT_GATHER=rccl|peer|host   how the bands reach the host image (default: RCCL if it can)
@@ -123,12 +125,31 @@ int main(int argc, char** argv) {
     }
     int repeat = 0;
     if (const char* r = std::getenv("MRT_REPEAT")) repeat = std::atoi(r);
+    int accel_method = -1;
+    if (const char* m = std::getenv("MRT_ACCEL")) {
+        if (!std::strcmp(m, "grid")) accel_method = MRT_ACCEL_GRID;
+        else if (!std::strcmp(m, "cull")) accel_method = MRT_ACCEL_TILE_CULL;
+        else if (!std::strcmp(m, "block")) accel_method = MRT_ACCEL_BLOCK_REJECT;
+        else {
+            std::cerr << std::endl << "error: MRT_ACCEL must be grid, cull or block" << std::endl;
+            mrt_scene_free(loaded);
+            return 1;
+        }
+        if (multi) {
+            std::cerr << std::endl << "error: MRT_ACCEL renders on one GPU; unset MRT_GPUS / MRT_GPU_LIST" << std::endl;
+            mrt_scene_free(loaded);
+            return 1;
+        }
+    }
+    const bool accel = accel_method >= 0;
 
     const size_t n_bytes = static_cast<size_t>(scene->xres) * scene->yres * 4;
     mrt_stats stats{};
     mrt_multi_stats mstats{};
+    mrt_accel_stats astats{};
     mrt_ctx* ctx = nullptr;
     mrt_multi* mctx = nullptr;
+    mrt_accel* actx = nullptr;
     void* pinned = nullptr;
     double best_ms = 0.0;
     const auto t_create = clk::now();
@@ -136,6 +157,9 @@ int main(int argc, char** argv) {
     if (multi) {
         mrt_multi_config mc = {n_gpus, gpu_list.empty() ? nullptr : gpu_list.data(), flags, 0u, gather};
         rc = mrt_multi_create(&mc, &mctx);
+    } else if (accel) {
+        mrt_accel_config ac = {-1, static_cast<uint32_t>(accel_method), 0u};
+        rc = mrt_accel_create(&ac, &actx);
     } else {
         mrt_config cfg = {-1, flags};
         rc = mrt_create(&cfg, &ctx);
@@ -144,9 +168,13 @@ int main(int argc, char** argv) {
     const double create_ms = ms_since(t_create);       // HIP start-up, streams, page-locked frame buffer
     uint8_t* pixels = static_cast<uint8_t*>(pinned);
     auto render_once = [&]() {
-        return multi ? mrt_multi_render_rgba8(mctx, pixels, &mstats) : mrt_render_rgba8(ctx, pixels, &stats);
+        if (multi) return mrt_multi_render_rgba8(mctx, pixels, &mstats);
+        if (!accel) return mrt_render_rgba8(ctx, pixels, &stats);
+        const int r = mrt_accel_render_rgba8(actx, pixels, &astats);
+        stats = astats.frame;
+        return r;
     };
-    if (rc == MRT_OK) rc = multi ? mrt_multi_set_scene(mctx, scene) : mrt_set_scene(ctx, scene);
+    if (rc == MRT_OK) rc = multi ? mrt_multi_set_scene(mctx, scene) : accel ? mrt_accel_set_scene(actx, scene) : mrt_set_scene(ctx, scene);
     if (rc == MRT_OK) rc = render_once();
     for (int k = 0; k < repeat && rc == MRT_OK; ++k) {
         const auto t_frame = clk::now();
@@ -158,10 +186,11 @@ int main(int argc, char** argv) {
         mrt_host_free(pinned);
         mrt_destroy(ctx);
         mrt_multi_destroy(mctx);
+        mrt_accel_destroy(actx);
         mrt_scene_free(loaded);
     };
     if (rc != MRT_OK) {
-        const char* why = multi ? mrt_multi_last_error(mctx) : mrt_last_error(ctx);
+        const char* why = multi ? mrt_multi_last_error(mctx) : accel ? mrt_accel_last_error(actx) : mrt_last_error(ctx);
         std::cerr << std::endl << "error: render failed: " << why << std::endl;
         cleanup();
         return 1;
@@ -194,10 +223,12 @@ int main(int argc, char** argv) {
             std::fprintf(stderr,
                          "{\"rays\": %llu, \"prim_tests\": %llu, \"load_ms\": %.3f, \"create_ms\": %.3f, "
                          "\"upload_ms\": %.4f, \"trace_ms\": %.4f, \"shade_ms\": %.4f, \"download_ms\": %.4f, "
-                         "\"best_frame_ms\": %.4f, \"png_ms\": %.3f, \"total_ms\": %.3f, \"mrays_per_s\": %.2f}\n",
+                         "\"best_frame_ms\": %.4f, \"png_ms\": %.3f, \"total_ms\": %.3f, \"mrays_per_s\": %.2f, "
+                         "\"kernel\": %u, \"grid_build_ms\": %.4f, \"grid_cells\": %llu, \"grid_refs\": %llu}\n",
                          (unsigned long long)stats.rays, (unsigned long long)stats.prim_tests, load_ms, create_ms,
                          stats.upload_ms, stats.trace_ms, stats.shade_ms, stats.download_ms, best_ms, png_ms,
-                         ms_since(t_start), stats.kernel_ms > 0 ? stats.rays / stats.kernel_ms * 1e-3 : 0.0);
+                         ms_since(t_start), stats.kernel_ms > 0 ? stats.rays / stats.kernel_ms * 1e-3 : 0.0,
+                         stats.kernel, astats.build_ms, (unsigned long long)astats.cells, (unsigned long long)astats.refs);
         }
     }
     cleanup();

@@ -70,8 +70,10 @@ def test_multi_auto_transport_and_flags(mrt):
         assert np.array_equal(m.render()[0], want)
     finally:
         m.close()
-    # the other kernels, rank by rank (bands of 32 rows keep the tile cull eligible)
-    for flags in (mrt.FLAG_FULL_TEST, mrt.FLAG_SCREEN_CULL, mrt.FLAG_BLOCK_REJECT):
+    # the other brute-force kernels, rank by rank; the reserved flag bits are refused
+    with pytest.raises(mrt.MrtError):
+        mrt.MultiContext(devices=[0, 0], flags=mrt.RESERVED_FLAG_BITS)
+    for flags in (mrt.FLAG_FULL_TEST, mrt.FLAG_NO_CIRCLE):
         m = mrt.MultiContext(devices=[0, 0, 0], flags=flags, band_rows_=32, gather=mrt.GATHER_HOST)
         try:
             m.set_scene(sc)

@@ -104,15 +104,17 @@ def test_prefilter_is_a_superset_of_exact(mrt, oracle):
 
 
 def test_block_reject_flag_changes_nothing(mrt, oracle):
-    """MRT_FLAG_BLOCK_REJECT (opt-in 4x4 block culling) and MRT_FLAG_NO_CIRCLE (no bounding-circle
-    level) must give the same winners, t and bytes as the default path, including with band
-    heights that are not multiples of 4."""
+    """The accelerated entry points (mrt_accel_*: 4x4 block reject, 32x32 tile cull, screen-space
+    grid), MRT_FLAG_NO_CIRCLE (no bounding-circle level) and MRT_FLAG_FULL_TEST must give the same
+    winners, t and bytes as the default path, including with band heights that are not multiples of
+    4 or 32."""
     import torch
     a = mrt.Context(device=0, flags=mrt.FLAG_COUNT_EXACT)
-    b = mrt.Context(device=0, flags=mrt.FLAG_BLOCK_REJECT | mrt.FLAG_COUNT_EXACT)
+    b = mrt.Accel(device=0, method="block", flags=mrt.FLAG_COUNT_EXACT)
     c = mrt.Context(device=0, flags=mrt.FLAG_NO_CIRCLE | mrt.FLAG_COUNT_EXACT)
-    d = mrt.Context(device=0, flags=mrt.FLAG_SCREEN_CULL | mrt.FLAG_COUNT_EXACT)
+    d = mrt.Accel(device=0, method="cull", flags=mrt.FLAG_COUNT_EXACT)
     e = mrt.Context(device=0, flags=mrt.FLAG_FULL_TEST | mrt.FLAG_COUNT_EXACT)
+    f = mrt.Accel(device=0, method="grid", flags=mrt.FLAG_COUNT_EXACT)
     try:
         rng = np.random.default_rng(5)
         cases = [scene_py.load_scene(SCENES / "teatime.json", xres=1280, yres=720,
@@ -133,11 +135,20 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
             assert_same_hits(ra, rc)
             assert np.array_equal(ra["rgba"], rc["rgba"])
             assert rc["stats"].exact_tests == ra["stats"].exact_tests
-            rd = gpu_render(d, sc)                                        # opt-in tile culling
+            rd = gpu_render(d, sc)                                        # tile culling
             assert rd["stats"].kernel == mrt.KERNEL_CULL
             assert_same_hits(ra, rd)
             assert np.array_equal(ra["rgba"], rd["rgba"])
             assert rd["stats"].exact_tests <= ra["stats"].exact_tests * 1.01 + 64
+            rf = gpu_render(f, sc)                                        # screen-space grid
+            assert rf["stats"].kernel == mrt.KERNEL_GRID
+            assert_same_hits(ra, rf)
+            assert np.array_equal(ra["rgba"], rf["rgba"])
+            # same tile tests, same survivors -- except that the grid does not list what only touches
+            # the padding rows and columns of the last tiles
+            assert 0.99 * rd["stats"].exact_tests <= rf["stats"].exact_tests <= rd["stats"].exact_tests
+            n_cells = ((sc.struct.xres + 31) // 32) * ((sc.struct.yres + 31) // 32)
+            assert rf["stats"].cells == n_cells and 0 < rf["stats"].refs < n_cells * sc.n_objects
             re_ = gpu_render(e, sc)                                       # determinants for every pair
             assert re_["stats"].kernel == mrt.KERNEL_FULL
             assert_same_hits(ra, re_)
@@ -166,6 +177,19 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
                 assert stb.kernel == (mrt.KERNEL_CULL if band == 32 else mrt.KERNEL_TRACE)
             torch.cuda.synchronize()
             assert np.array_equal(mrt.bands_to_image(g.cpu().numpy(), stride, 1280, 720, band, 3), full)
+        # the grid needs the same of interleaved bands, and says so instead of falling back
+        f.set_scene(sc)
+        rows = [mrt.band_rows(720, 32, r, 3) for r in range(3)]
+        stride = max(rows) * 1280 * 4
+        g = torch.zeros((3, stride), dtype=torch.uint8, device="cuda:0")
+        for r in range(3):
+            stb = f.render_bands_device(32, r, 3, g[r].data_ptr(), stride, timed=True)
+            assert stb.kernel == mrt.KERNEL_GRID
+        torch.cuda.synchronize()
+        assert np.array_equal(mrt.bands_to_image(g.cpu().numpy(), stride, 1280, 720, 32, 3), full)
+        with pytest.raises(mrt.MrtError) as err:
+            f.render_bands_device(6, 0, 3, g[0].data_ptr(), stride)
+        assert err.value.code == -1 and "32" in err.value.message
         e.set_scene(sc)
         rows = [mrt.band_rows(720, 6, r, 2) for r in range(2)]
         stride = max(rows) * 1280 * 4
@@ -180,6 +204,7 @@ def test_block_reject_flag_changes_nothing(mrt, oracle):
         c.close()
         d.close()
         e.close()
+        f.close()
 
 
 def test_degenerate_and_edge_on_triangles(gpu_ctx, mrt, oracle):
@@ -279,8 +304,7 @@ def test_negative_zero_barycentric_is_a_hit(mrt, oracle):
     tests `beta < 0`, which -0 passes, so those pixels hit although they lie (by 1e-43) outside the
     triangle.  Every kernel must reproduce it: none of the rejection tests may drop a pair on
     the sign of a numerator alone.  With a viewport 2^130 times larger the same pixels miss."""
-    flag_sets = (0, mrt.FLAG_FULL_TEST, mrt.FLAG_SCREEN_CULL, mrt.FLAG_BLOCK_REJECT, mrt.FLAG_NO_CIRCLE,
-                 mrt.FLAG_NO_PREFILTER)
+    flag_sets = (0, mrt.FLAG_FULL_TEST, "cull", "block", "grid", mrt.FLAG_NO_CIRCLE, mrt.FLAG_NO_PREFILTER)
     tri = np.array([[0, -0.3, -1, -1e30, -0.3, -1, 0, 0.7, -1]], dtype=np.float64).T
     for e, expect_all in ((2.0 ** -140, True), (2.0 ** -10, False)):
         sc = mrt.Scene(eye=[0, 0, 0], u=[1, 0, 0], v=[0, 1, 0], w=[0, 0, 1], xres=4, yres=2, left=-e, right=e,
@@ -290,7 +314,7 @@ def test_negative_zero_barycentric_is_a_hit(mrt, oracle):
         assert bool((o["ids"] == 0).all()) == expect_all
         assert (o["ids"][:, 0] == 0).all()              # the first column is inside either way
         for flags in flag_sets:
-            ctx = mrt.Context(device=0, flags=flags)
+            ctx = mrt.renderer(device=0, kind=flags)
             try:
                 r = gpu_render(ctx, sc)
             finally:
@@ -300,13 +324,11 @@ def test_negative_zero_barycentric_is_a_hit(mrt, oracle):
             assert np.array_equal(r["rgba"], o["rgba"])
 
 
-def _expected_kernel(mrt, flags):
-    """The kernel a whole-frame render runs for these ctx flags."""
-    if flags & mrt.FLAG_FULL_TEST:
-        return mrt.KERNEL_FULL
-    if flags & mrt.FLAG_SCREEN_CULL and not flags & mrt.FLAG_NO_PREFILTER:
-        return mrt.KERNEL_CULL
-    return mrt.KERNEL_TRACE_BLOCK if flags & mrt.FLAG_BLOCK_REJECT else mrt.KERNEL_TRACE
+def _expected_kernel(mrt, kind):
+    """The kernel a whole-frame render runs: ctx flags (an integer) or an mrt_accel method (a name)."""
+    if isinstance(kind, str):
+        return {"cull": mrt.KERNEL_CULL, "block": mrt.KERNEL_TRACE_BLOCK, "grid": mrt.KERNEL_GRID}[kind]
+    return mrt.KERNEL_FULL if kind & mrt.FLAG_FULL_TEST else mrt.KERNEL_TRACE
 
 
 def test_non_finite_and_odd_inputs(mrt, oracle):
@@ -325,7 +347,7 @@ def test_non_finite_and_odd_inputs(mrt, oracle):
                     [nan, 0, -2, 0.3],
                     [0.8, -0.5, -2, 0.0],
                     [0.5, 0.6, -2.2, 0.3]], dtype=np.float64).T
-    flag_sets = (0, mrt.FLAG_FULL_TEST, mrt.FLAG_SCREEN_CULL, mrt.FLAG_BLOCK_REJECT, mrt.FLAG_NO_PREFILTER)
+    flag_sets = (0, mrt.FLAG_FULL_TEST, "cull", "block", "grid", mrt.FLAG_NO_PREFILTER)
     for proj in (mrt.PROJ_PERSP, mrt.PROJ_ORTHO):
         sc = mrt.Scene(eye=[0, 0, 0], u=[1, 0, 0], v=[0, 1, 0], w=[0, 0, 1], xres=96, yres=64, left=-1.2,
                        right=1.2, top=0.8, bottom=-0.8, projection=proj, focal=1.0, shader=mrt.SHADER_PHONG,
@@ -336,7 +358,7 @@ def test_non_finite_and_odd_inputs(mrt, oracle):
         o = oracle.render(sc)
         assert len(np.unique(o["ids"])) >= 3          # the NaN-radius sphere "hits" at t = -b/a wherever that is > 0
         for flags in flag_sets:
-            ctx = mrt.Context(device=0, flags=flags)
+            ctx = mrt.renderer(device=0, kind=flags)
             try:
                 r = gpu_render(ctx, sc)
             finally:
@@ -365,9 +387,9 @@ def test_equal_t_goes_to_the_lower_object_id(mrt, oracle):
                                                           np.full(7, 0.5), np.full(7, 4.0)])
         o = oracle.render(sc)
         assert len(np.unique(o["ids"])) > 20
-        for flags in (mrt.FLAG_FULL_TEST, 0, mrt.FLAG_SCREEN_CULL, mrt.FLAG_NO_PREFILTER):
+        for flags in (mrt.FLAG_FULL_TEST, 0, "cull", "grid", mrt.FLAG_NO_PREFILTER):
             for _ in range(4 if flags == mrt.FLAG_FULL_TEST else 1):
-                ctx = mrt.Context(device=0, flags=flags)
+                ctx = mrt.renderer(device=0, kind=flags)
                 try:
                     r = gpu_render(ctx, sc)
                 finally:
@@ -428,9 +450,9 @@ def test_teatime_4k_full_frame_against_oracle(gpu_ctx, mrt, oracle):
     assert_same_hits(r, o)
     stats = check(r["rgba"], o["rgba"], o["ids"])
     assert stats["within_1lsb"] == stats["pixels"]
-    # the other kernels on the same frame: determinants for every pair, and the opt-in tile cull
-    for flags in (mrt.FLAG_FULL_TEST, mrt.FLAG_SCREEN_CULL, mrt.FLAG_BLOCK_REJECT):
-        ctx = mrt.Context(device=0, flags=flags)
+    # the other kernels on the same frame: a 3x3 solve for every pair, and the accelerated entry points
+    for flags in (mrt.FLAG_FULL_TEST, "cull", "block", "grid"):
+        ctx = mrt.renderer(device=0, kind=flags)
         try:
             r2 = gpu_render(ctx, ls)
         finally:
@@ -467,17 +489,20 @@ def test_soup_16k_rows_against_oracle(mrt, oracle):
         assert np.array_equal(ids[y], o["ids"][y])
         assert np.array_equal(t[y], o["t"][y])
         check(img[y:y + 1], o["rgba"][y:y + 1], o["ids"][y:y + 1])
-    # size-independent property at the full size: the tile-cull kernel must reproduce all
-    # 268 435 456 winners and t values of the default kernel
-    ctx = mrt.Context(device=0, flags=mrt.FLAG_SCREEN_CULL)
-    try:
-        ctx.set_scene(sc)
-        img2, ids2, t2, _ = ctx.render(want_ids=True)
-    finally:
-        ctx.close()
-    assert np.array_equal(ids2, ids) and np.array_equal(t2.view(np.uint32), t.view(np.uint32))
-    assert np.array_equal(img2, img)
-    del img, ids, t, img2, ids2, t2
+    # size-independent property at the full size: the tile-cull and grid kernels must reproduce
+    # all 268 435 456 winners and t values of the default kernel
+    for method in ("cull", "grid"):
+        ctx = mrt.Accel(device=0, method=method)
+        try:
+            ctx.set_scene(sc)
+            img2, ids2, t2, st2 = ctx.render(want_ids=True)
+        finally:
+            ctx.close()
+        assert np.array_equal(ids2, ids) and np.array_equal(t2.view(np.uint32), t.view(np.uint32)), method
+        assert np.array_equal(img2, img), method
+        del img2, ids2, t2
+    assert st2.kernel == mrt.KERNEL_GRID and st2.cells == 512 * 512 and st2.refs < 40 * st2.cells
+    del img, ids, t
 
 
 def test_set_camera_equals_fresh_scene(mrt, oracle):

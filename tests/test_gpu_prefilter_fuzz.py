@@ -89,8 +89,9 @@ def _scene(mrt, rng, kind, proj):
                                   "grazing_hires", "micro", "denormal", "giant"])
 def test_prefilters_never_drop_an_exact_hit(mrt, kind):
     fast = mrt.Context(device=0)
-    blk = mrt.Context(device=0, flags=mrt.FLAG_BLOCK_REJECT)
-    cull = mrt.Context(device=0, flags=mrt.FLAG_SCREEN_CULL)
+    blk = mrt.Accel(device=0, method="block")
+    cull = mrt.Accel(device=0, method="cull")
+    grid = mrt.Accel(device=0, method="grid")
     full = mrt.Context(device=0, flags=mrt.FLAG_FULL_TEST)
     exact = mrt.Context(device=0, flags=mrt.FLAG_NO_PREFILTER)
     rng = np.random.default_rng(zlib.crc32(kind.encode()))
@@ -102,7 +103,7 @@ def test_prefilters_never_drop_an_exact_hit(mrt, kind):
             exact.set_scene(sc)
             _, ids_e, t_e, _ = exact.render(want_ids=True)
             for ctx, kernel in ((fast, mrt.KERNEL_TRACE), (blk, mrt.KERNEL_TRACE_BLOCK), (cull, mrt.KERNEL_CULL),
-                                (full, mrt.KERNEL_FULL)):
+                                (grid, mrt.KERNEL_GRID), (full, mrt.KERNEL_FULL)):
                 ctx.set_scene(sc)
                 _, ids_f, t_f, st_f = ctx.render(want_ids=True)
                 assert st_f.kernel == kernel       # any frame height gets the kernel its flags ask for
@@ -115,5 +116,6 @@ def test_prefilters_never_drop_an_exact_hit(mrt, kind):
         fast.close()
         blk.close()
         cull.close()
+        grid.close()
         full.close()
         exact.close()

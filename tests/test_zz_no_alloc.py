@@ -67,23 +67,13 @@ def test_noalloc_other_kernels_and_limits(mrt):
     import torch
     sc = mrt.LoadedScene(text=mkscene.teatime(640, 360)).copy()
     # the kernels that work in the key plane (and the one that needs no plane at all) are served
-    for flags in (mrt.FLAG_BLOCK_REJECT, mrt.FLAG_NO_CIRCLE, mrt.FLAG_FULL_TEST, mrt.FLAG_COUNT_EXACT):
+    for flags in (mrt.FLAG_NO_CIRCLE, mrt.FLAG_FULL_TEST, mrt.FLAG_COUNT_EXACT):
         ctx = mrt.Context(device=0, flags=flags)
         try:
             ref, out = _both(mrt, ctx, sc, 360, 0, 1)
             assert np.array_equal(out, ref), flags
         finally:
             ctx.close()
-    # the tile cull needs planes of its own: refused, with a message
-    ctx = mrt.Context(device=0, flags=mrt.FLAG_SCREEN_CULL)
-    try:
-        ctx.set_scene(sc)
-        buf = torch.zeros(640 * 360 * 4, dtype=torch.uint8, device="cuda:0")
-        with pytest.raises(mrt.MrtError) as e:
-            ctx.render_bands_device_noalloc(360, 0, 1, buf.data_ptr(), buf.numel())
-        assert e.value.code == -1 and "SCREEN_CULL" in e.value.message
-    finally:
-        ctx.close()
     # beyond the fixed array: 7680 x 4320 needs 33.4 M keys, the array holds 8 M
     ctx = mrt.Context(device=0)
     try:
