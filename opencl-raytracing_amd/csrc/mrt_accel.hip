@@ -59,70 +59,128 @@ __device__ __forceinline__ bool tile_range(float a, float b, uint32_t extent, ui
     return lo <= hi;
 }
 
-// One wave per object (spheres first, gfxraytrace.hpp:701-714); the lanes stride over the tiles
-// of the bounding box of its prefilter region and run the tile test on each.  FILL == false
-// counts the tiles that pass per cell; FILL == true appends the object id to each such cell's
-// list at the cell's cursor (which starts at the cell's offset).  Both passes evaluate the same
-// expressions on the same inputs, so they agree tile for tile.
-template <bool FILL>
-__global__ __launch_bounds__(64 * kBinWaves) void grid_bin_kernel(const RenderParams p, uint32_t tiles_x,
-                                                                 uint32_t tiles_y, uint32_t* __restrict__ cell_cursor,
-                                                                 uint32_t* __restrict__ refs,
-                                                                 const unsigned long long* __restrict__ n_refs,
-                                                                 unsigned long long capacity) {
-    // A fill enqueued before the host knows the reference count: skipped as a whole when the lists
-    // would not fit the buffer it was given.
-    if (FILL && n_refs != nullptr && *n_refs > capacity) return;
-    const uint32_t obj = blockIdx.x * kBinWaves + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
-    if (obj >= p.n_sph + p.n_tri) return;
-    const bool sphere = obj < p.n_sph;
-    uint32_t tx0 = 0, tx1 = tiles_x - 1, ty0 = 0, ty1 = tiles_y - 1;
-    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* rec = nullptr;
-    if (sphere) {
+// The box of tiles [tx0, tx1] x [ty0, ty1] that bounds the prefilter region of object obj
+// (spheres first, gfxraytrace.hpp:701-714), and what the tile test needs: e is the sphere's
+// ellipse record or the triangle's bounding circle, rec the triangle's edge record.  False when
+// the object cannot touch the image.
+struct TileBox {
+    uint32_t tx0, tx1, ty0, ty1;
+    float4 e;
+    const float4* rec;
+    bool sphere;
+};
+
+__device__ __forceinline__ bool object_tile_box(const RenderParams& p, uint32_t obj, uint32_t tiles_x, uint32_t tiles_y,
+                                                TileBox& b) {
+    b.sphere = obj < p.n_sph;
+    b.tx0 = 0; b.tx1 = tiles_x - 1; b.ty0 = 0; b.ty1 = tiles_y - 1;
+    b.rec = nullptr;
+    if (b.sphere) {
         // (x*sx + ox)^2 + (y*sy + oy)^2 <= 1 needs |x*sx + ox| <= 1: an interval of x, taken with
         // one pixel plus 1e-5 of its own size as slack (the tile test allows 1.000001, and both
         // it and the per-pixel test round)
-        e = p.sph_filter[obj];
+        const float4 e = p.sph_filter[obj];
+        b.e = e;
         if (e.x != 0.0f) {
-            const float a = (-1.0f - e.y) / e.x, b = (1.0f - e.y) / e.x;
-            const float pad = 1.0f + 1e-5f * (fabsf(a) + fabsf(b));
-            if (!tile_range(fminf(a, b) - pad, fmaxf(a, b) + pad, p.xres, tiles_x, tx0, tx1)) return;
+            const float lo = (-1.0f - e.y) / e.x, hi = (1.0f - e.y) / e.x;
+            const float pad = 1.0f + 1e-5f * (fabsf(lo) + fabsf(hi));
+            if (!tile_range(fminf(lo, hi) - pad, fmaxf(lo, hi) + pad, p.xres, tiles_x, b.tx0, b.tx1)) return false;
         } else if (!(fabsf(e.y) <= 1.000001f)) {
-            return;
+            return false;
         }
         if (e.z != 0.0f) {
-            const float a = (-1.0f - e.w) / e.z, b = (1.0f - e.w) / e.z;
-            const float pad = 1.0f + 1e-5f * (fabsf(a) + fabsf(b));
-            if (!tile_range(fminf(a, b) - pad, fmaxf(a, b) + pad, p.yres, tiles_y, ty0, ty1)) return;
+            const float lo = (-1.0f - e.w) / e.z, hi = (1.0f - e.w) / e.z;
+            const float pad = 1.0f + 1e-5f * (fabsf(lo) + fabsf(hi));
+            if (!tile_range(fminf(lo, hi) - pad, fmaxf(lo, hi) + pad, p.yres, tiles_y, b.ty0, b.ty1)) return false;
         } else if (!(fabsf(e.w) <= 1.000001f)) {
-            return;
+            return false;
         }
     } else {
         const uint32_t ti = obj - p.n_sph;
-        e = p.tri_circle[ti];                        // (xc, yc, R^2): 1e30 = every pixel, negative = none
-        rec = p.tri_filter + (size_t)ti * 3;
-        if (e.z < 0.0f) return;
+        const float4 e = p.tri_circle[ti];           // (xc, yc, R^2): 1e30 = every pixel, negative = none
+        b.e = e;
+        b.rec = p.tri_filter + (size_t)ti * 3;
+        if (e.z < 0.0f) return false;
         if (e.z < 1e29f) {
             // the circle's bounding box, with a pixel and the rounding of centre -+ radius as slack
             const float r = sqrtf(e.z) * 1.00001f + 1.0f;
             const float px = 1e-6f * fabsf(e.x), py = 1e-6f * fabsf(e.y);
-            if (!tile_range(e.x - r - px, e.x + r + px, p.xres, tiles_x, tx0, tx1)) return;
-            if (!tile_range(e.y - r - py, e.y + r + py, p.yres, tiles_y, ty0, ty1)) return;
+            if (!tile_range(e.x - r - px, e.x + r + px, p.xres, tiles_x, b.tx0, b.tx1)) return false;
+            if (!tile_range(e.y - r - py, e.y + r + py, p.yres, tiles_y, b.ty0, b.ty1)) return false;
         }
     }
-    const uint32_t nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
+    return true;
+}
+
+// Tiles first, first + stride, ... of the box: the tile test, and for every tile that passes one
+// more reference in its cell -- counted (FILL == false) or written at the cell's cursor, which
+// starts at the cell's offset (FILL == true).  Both passes evaluate the same expressions on the
+// same inputs, so they agree tile for tile.
+template <bool FILL>
+__device__ __forceinline__ void bin_tiles(const TileBox& b, uint32_t obj, uint32_t first, uint32_t stride,
+                                          uint32_t tiles_x, uint32_t* __restrict__ cell_cursor,
+                                          uint32_t* __restrict__ refs) {
+    const uint32_t nx = b.tx1 - b.tx0 + 1, ny = b.ty1 - b.ty0 + 1;
     const uint32_t total = nx * ny;                  // at most 2048 x 2048
-    for (uint32_t i = lane; i < total; i += 64) {
+    for (uint32_t i = first; i < total; i += stride) {
         const uint32_t ry = i / nx, rx = i - ry * nx;
-        const uint32_t tx = tx0 + rx, ty = ty0 + ry;
+        const uint32_t tx = b.tx0 + rx, ty = b.ty0 + ry;
         const float txf = (float)(tx * kWaveTile), tyf = (float)(ty * kWaveTile);
-        const bool pass = sphere ? tile_may_hit_sphere(e, txf, tyf) : tile_may_hit_triangle(e, rec, txf, tyf);
+        const bool pass = b.sphere ? tile_may_hit_sphere(b.e, txf, tyf) : tile_may_hit_triangle(b.e, b.rec, txf, tyf);
         if (pass) {
             const uint32_t at = atomicAdd(&cell_cursor[ty * tiles_x + tx], 1u);
             if (FILL) refs[at] = obj;
         }
+    }
+}
+
+// Objects whose box holds more tiles than this are left to grid_bin_big_kernel: one wave walking
+// a quarter of a million tiles (a triangle seen edge-on has a record every tile passes) would
+// keep the whole build waiting.
+constexpr uint32_t kBigBoxTiles = 2048;
+
+// One wave per object; the lanes stride over the tiles of its box.  The counting pass also
+// collects the objects with a big box in big_list.  n_refs / capacity: a fill enqueued before
+// the host knows the reference count is skipped as a whole when the lists would not fit the
+// buffer it was given.
+template <bool FILL>
+__global__ __launch_bounds__(64 * kBinWaves) void grid_bin_kernel(const RenderParams p, uint32_t tiles_x,
+                                                                 uint32_t tiles_y, uint32_t* __restrict__ cell_cursor,
+                                                                 uint32_t* __restrict__ refs,
+                                                                 uint32_t* __restrict__ big_list,
+                                                                 uint32_t* __restrict__ big_count,
+                                                                 const unsigned long long* __restrict__ n_refs,
+                                                                 unsigned long long capacity) {
+    if (FILL && n_refs != nullptr && *n_refs > capacity) return;
+    const uint32_t obj = blockIdx.x * kBinWaves + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (obj >= p.n_sph + p.n_tri) return;
+    TileBox b;
+    if (!object_tile_box(p, obj, tiles_x, tiles_y, b)) return;
+    if ((b.tx1 - b.tx0 + 1) * (b.ty1 - b.ty0 + 1) > kBigBoxTiles) {
+        if (!FILL && lane == 0) big_list[atomicAdd(big_count, 1u)] = obj;
+        return;
+    }
+    bin_tiles<FILL>(b, obj, lane, 64, tiles_x, cell_cursor, refs);
+}
+
+// The objects with a big box, one after the other, each over all threads of the launch.
+template <bool FILL>
+__global__ __launch_bounds__(256) void grid_bin_big_kernel(const RenderParams p, uint32_t tiles_x, uint32_t tiles_y,
+                                                          uint32_t* __restrict__ cell_cursor,
+                                                          uint32_t* __restrict__ refs,
+                                                          const uint32_t* __restrict__ big_list,
+                                                          const uint32_t* __restrict__ big_count,
+                                                          const unsigned long long* __restrict__ n_refs,
+                                                          unsigned long long capacity) {
+    if (FILL && n_refs != nullptr && *n_refs > capacity) return;
+    const uint32_t n_big = *big_count;
+    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint32_t k = 0; k < n_big; ++k) {
+        const uint32_t obj = big_list[k];
+        TileBox b;
+        if (!object_tile_box(p, obj, tiles_x, tiles_y, b)) continue;
+        bin_tiles<FILL>(b, obj, first, stride, tiles_x, cell_cursor, refs);
     }
 }
 
@@ -227,6 +285,9 @@ struct mrt_accel {
     unsigned long long* d_block_sum = nullptr;   // 1024 scan partials + the total
     uint32_t* d_refs = nullptr;
     size_t cap_cells = 0, cap_refs = 0;
+    uint32_t* d_big = nullptr;               // objects whose box is too big for one wave, and their count
+    uint32_t* d_big_count = nullptr;
+    size_t cap_big = 0;
     unsigned long long* h_total = nullptr;   // page-locked word the total is read back into
     uint64_t n_refs = 0;
     double build_ms = 0.0;
@@ -279,6 +340,7 @@ int base_failed(mrt_accel* a, int rc) { return afail(a, rc, mrt_last_error(a->ba
 
 // At most 2^28 (tile, primitive) references, 1 GiB of ids.
 constexpr uint64_t kMaxRefs = 1ull << 28;
+constexpr uint32_t kBigBlocks = 1024;        // blocks of grid_bin_big_kernel
 
 // Completes a build enqueued by build_grid: waits for it, reads the reference count, and -- only
 // when the lists did not fit the buffer the speculative fill had (or there was none yet) -- grows
@@ -310,6 +372,10 @@ int finish_build(mrt_accel* a) {
         const uint32_t n_obj = p.n_sph + p.n_tri;
         hipLaunchKernelGGL(mrt::grid_bin_kernel<true>, dim3((n_obj + mrt::kBinWaves - 1) / mrt::kBinWaves),
                            dim3(64 * mrt::kBinWaves), 0, s, p, a->tiles_x, a->tiles_y, a->d_cursor, a->d_refs,
+                           a->d_big, a->d_big_count, (const unsigned long long*)nullptr, 0ull);
+        AHIP_TRY(a, hipGetLastError());
+        hipLaunchKernelGGL(mrt::grid_bin_big_kernel<true>, dim3(kBigBlocks), dim3(256), 0, s, p, a->tiles_x, a->tiles_y,
+                           a->d_cursor, a->d_refs, (const uint32_t*)a->d_big, (const uint32_t*)a->d_big_count,
                            (const unsigned long long*)nullptr, 0ull);
         AHIP_TRY(a, hipGetLastError());
         AHIP_TRY(a, hipEventRecord(a->ev[1], s));
@@ -354,15 +420,26 @@ int build_grid(mrt_accel* a) {
         AHIP_TRY(a, hipMalloc((void**)&a->d_start, (cells + 1) * sizeof(uint32_t)));
         a->cap_cells = cells;
     }
+    if (n_obj > a->cap_big) {
+        if (a->d_big) { (void)hipFree(a->d_big); a->d_big = nullptr; }
+        a->cap_big = 0;
+        AHIP_TRY(a, hipMalloc((void**)&a->d_big, (size_t)n_obj * sizeof(uint32_t)));
+        a->cap_big = n_obj;
+    }
     const uint32_t n_blocks = (uint32_t)((cells + mrt::kScanTile - 1) / mrt::kScanTile);     // <= 1024 for 65536^2 pixels
     if (n_blocks > 1024) return afail(a, MRT_ERR_TOO_LARGE, "grid has more than 4 Mi cells");
     AHIP_TRY(a, hipEventRecord(a->ev[0], s));
     AHIP_TRY(a, hipMemsetAsync(a->d_cursor, 0, cells * sizeof(uint32_t), s));
     const dim3 bgrid((n_obj + mrt::kBinWaves - 1) / mrt::kBinWaves), bblock(64 * mrt::kBinWaves);
     unsigned long long* d_total = a->d_block_sum + 1024;
+    AHIP_TRY(a, hipMemsetAsync(a->d_big_count, 0, sizeof(uint32_t), s));
     if (n_obj) {
         hipLaunchKernelGGL(mrt::grid_bin_kernel<false>, bgrid, bblock, 0, s, p, a->tiles_x, a->tiles_y, a->d_cursor,
-                           (uint32_t*)nullptr, (const unsigned long long*)nullptr, 0ull);
+                           (uint32_t*)nullptr, a->d_big, a->d_big_count, (const unsigned long long*)nullptr, 0ull);
+        AHIP_TRY(a, hipGetLastError());
+        hipLaunchKernelGGL(mrt::grid_bin_big_kernel<false>, dim3(kBigBlocks), dim3(256), 0, s, p, a->tiles_x, a->tiles_y,
+                           a->d_cursor, (uint32_t*)nullptr, (const uint32_t*)a->d_big, (const uint32_t*)a->d_big_count,
+                           (const unsigned long long*)nullptr, 0ull);
         AHIP_TRY(a, hipGetLastError());
     }
     hipLaunchKernelGGL(mrt::scan_block_sums, dim3(n_blocks), dim3(mrt::kScanBlock), 0, s, a->d_cursor, (uint32_t)cells,
@@ -376,7 +453,12 @@ int build_grid(mrt_accel* a) {
     AHIP_TRY(a, hipMemcpyAsync(a->h_total, d_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     if (n_obj && a->cap_refs) {
         hipLaunchKernelGGL(mrt::grid_bin_kernel<true>, bgrid, bblock, 0, s, p, a->tiles_x, a->tiles_y, a->d_cursor,
-                           a->d_refs, (const unsigned long long*)d_total, (unsigned long long)a->cap_refs);
+                           a->d_refs, a->d_big, a->d_big_count, (const unsigned long long*)d_total,
+                           (unsigned long long)a->cap_refs);
+        AHIP_TRY(a, hipGetLastError());
+        hipLaunchKernelGGL(mrt::grid_bin_big_kernel<true>, dim3(kBigBlocks), dim3(256), 0, s, p, a->tiles_x, a->tiles_y,
+                           a->d_cursor, a->d_refs, (const uint32_t*)a->d_big, (const uint32_t*)a->d_big_count,
+                           (const unsigned long long*)d_total, (unsigned long long)a->cap_refs);
         AHIP_TRY(a, hipGetLastError());
     }
     AHIP_TRY(a, hipEventRecord(a->ev[1], s));
@@ -519,6 +601,7 @@ int mrt_accel_create(const mrt_accel_config* cfg, mrt_accel** out) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&a->frame_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc((void**)&a->d_block_sum, (1024 + 1) * sizeof(unsigned long long));
         if (e == hipSuccess) e = hipMalloc((void**)&a->d_counter, sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc((void**)&a->d_big_count, sizeof(uint32_t));
         if (e == hipSuccess) e = hipHostMalloc((void**)&a->h_total, sizeof(unsigned long long), hipHostMallocDefault);
         if (e != hipSuccess) {
             const std::string msg = std::string("mrt_accel_create: ") + hipGetErrorString(e);
@@ -539,6 +622,8 @@ void mrt_accel_destroy(mrt_accel* a) {
         if (a->d_start) (void)hipFree(a->d_start);
         if (a->d_block_sum) (void)hipFree(a->d_block_sum);
         if (a->d_refs) (void)hipFree(a->d_refs);
+        if (a->d_big) (void)hipFree(a->d_big);
+        if (a->d_big_count) (void)hipFree(a->d_big_count);
         if (a->d_out) (void)hipFree(a->d_out);
         if (a->d_t) (void)hipFree(a->d_t);
         if (a->d_id) (void)hipFree(a->d_id);

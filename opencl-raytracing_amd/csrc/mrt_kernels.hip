@@ -843,7 +843,8 @@ __global__ __launch_bounds__(kBlockThreads) void cull_trace_kernel(const RenderP
 // pass -- but walks only its tile's list.  The prefilter records of a batch of
 // 32 listed objects are fetched by all lanes at once and staged in LDS, so the
 // per-object loop reads them as LDS broadcasts instead of waiting for one
-// scalar load after another.  The order of a list is whatever the binning
+// scalar load after another; the batches of a long list are dealt to the four
+// waves of the block.  The order of a list is whatever the binning
 // atomics gave: the keys make the winner independent of it.  The kernel shades
 // its own pixels (no (t, id) planes unless asked for): a cell with an empty list,
 // or one in which nothing was hit, is filled with the background colour; in the
@@ -867,76 +868,105 @@ __global__ __launch_bounds__(kBlockThreads) void grid_trace_kernel(const RenderP
     __shared__ float s_ux[kWaves][kWaveTile], s_uy[kWaves][kWaveTile];
     __shared__ uint32_t s_count[kWaves];
 
+    __shared__ uint32_t s_begin[kWaves], s_end[kWaves], s_hit[kWaves];
+    static_assert(kWaves == 4, "the batches of a list are dealt to the four waves of a block");
+
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    // Tile t of the block's 2x2, the cell it is, and the wave that owns it (wave t): sets it up,
+    // shades and stores it.  The lists are walked by all four waves (see below).
     const uint32_t wave_x0 = blockIdx.x * kBlockTileX + (wave & 1) * kWaveTile;
     const uint32_t wave_lr0 = blockIdx.y * kBlockTileY + (wave >> 1) * kWaveTile;
-    if (!((wave_x0 < p.xres) && (wave_lr0 < p.local_rows))) return;   // no block-level barriers in this kernel
-    TileState st;
-    st.keys = s_key[wave]; st.list = s_list[wave]; st.count = &s_count[wave];
-    st.tile_ux = s_ux[wave]; st.tile_uy = s_uy[wave];
-    st.bx = (lane & 7) * kLanePx; st.by = (lane >> 3) * kLanePx;
-    st.lane = lane;
-    const uint32_t x0 = wave_x0 + st.bx;
-    const uint32_t lr0 = wave_lr0 + st.by;
-    const uint32_t tile_row0 = image_row(p, wave_lr0);
-    st.xf = (float)x0;
-    st.yf0 = (float)tile_row0 + (float)st.by;
-    const uint32_t bg = shade_pixel<PROJ>(p, 0u, 0u, -1.0f, -1);       // the colour of a miss
-    const uint32_t cell = (tile_row0 / kWaveTile) * grid_tiles_x + wave_x0 / kWaveTile;
-    const uint32_t begin = cell_start[cell], end = cell_start[cell + 1];
-    if (begin == end) {                // nothing is listed for this cell
-        tile_background(p, bg, x0, lr0, t_out, id_out, pitch);
-        return;
+    const bool own_active = (wave_x0 < p.xres) && (wave_lr0 < p.local_rows);
+    TileState own;
+    own.keys = s_key[wave]; own.list = s_list[wave]; own.count = &s_count[wave];
+    own.tile_ux = s_ux[wave]; own.tile_uy = s_uy[wave];
+    own.bx = (lane & 7) * kLanePx; own.by = (lane >> 3) * kLanePx;
+    own.lane = lane;
+    own.xf = 0.0f; own.yf0 = 0.0f;
+    const uint32_t x0 = wave_x0 + own.bx;
+    const uint32_t lr0 = wave_lr0 + own.by;
+    uint32_t begin = 0, end = 0;
+    if (own_active) {
+        const uint32_t cell = (image_row(p, wave_lr0) / kWaveTile) * grid_tiles_x + wave_x0 / kWaveTile;
+        begin = cell_start[cell];
+        end = cell_start[cell + 1];
+        if (begin != end) tile_begin(p, own, wave_x0, wave_lr0);
     }
-    tile_begin(p, st, wave_x0, wave_lr0);
-    unsigned long long n_exact = 0;
-    bool recorded = false;
-    float4* batch = s_batch[wave];
+    if (lane == 0) {
+        s_begin[wave] = begin;
+        s_end[wave] = end;
+        s_hit[wave] = 0u;
+        s_count[wave] = 0u;
+    }
+    __syncthreads();
 
-    for (uint32_t base = begin; base < end; base += kGridBatch) {
-        const uint32_t n = (end - base) < (uint32_t)kGridBatch ? (end - base) : (uint32_t)kGridBatch;
-        const uint32_t ref = (uint32_t)lane < n ? refs[base + lane] : 0u;
-        // 96 record slots, two per lane: slot s is part s % 3 of listed object s / 3.  A sphere
-        // has one part (its ellipse), a triangle three (its edge record).
+    // A list is cut into batches of 32 objects and batch b of tile t goes to wave (t + b) % 4: a
+    // short list stays with the tile's own wave, a long one -- the pole of a mesh where a hundred
+    // thin triangles meet in one cell, whatever the resolution -- is shared by the block instead
+    // of holding the frame up.  The tile's keys take hits from any wave (LDS atomics).
+    unsigned long long n_exact = 0;
+    float4* batch = s_batch[wave];
+    for (int q = 0; q < kWaves; ++q) {
+        const int t = (wave + q) & 3;
+        const uint32_t t_begin = s_begin[t], t_end = s_end[t];
+        const uint32_t first = t_begin + (uint32_t)((wave - t) & 3) * kGridBatch;
+        if (first >= t_end) continue;
+        const uint32_t t_x0 = blockIdx.x * kBlockTileX + (t & 1) * kWaveTile;
+        const uint32_t t_lr0 = blockIdx.y * kBlockTileY + (t >> 1) * kWaveTile;
+        TileState st = own;
+        st.keys = s_key[t]; st.tile_ux = s_ux[t]; st.tile_uy = s_uy[t];
+        st.xf = (float)(t_x0 + own.bx);
+        st.yf0 = (float)image_row(p, t_lr0) + (float)own.by;
+        bool recorded = false;
+        for (uint32_t base = first; base < t_end; base += kWaves * kGridBatch) {
+            const uint32_t n = (t_end - base) < (uint32_t)kGridBatch ? (t_end - base) : (uint32_t)kGridBatch;
+            const uint32_t ref = (uint32_t)lane < n ? refs[base + lane] : 0u;
+            // 96 record slots, two per lane: slot s is part s % 3 of listed object s / 3.  A sphere
+            // has one part (its ellipse), a triangle three (its edge record).
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int s = lane + 64 * h;
-            const int k = s / 3, part = s - 3 * k;
-            const uint32_t obj = (uint32_t)__builtin_amdgcn_ds_bpermute(k << 2, (int)ref);
-            if (s < kGridBatch * 3 && (uint32_t)k < n) {
-                if (obj < p.n_sph) {
-                    if (part == 0) batch[s] = p.sph_filter[obj];
-                } else {
-                    batch[s] = p.tri_filter[(size_t)(obj - p.n_sph) * 3 + part];
+            for (int h = 0; h < 2; ++h) {
+                const int s = lane + 64 * h;
+                const int k = s / 3, part = s - 3 * k;
+                const uint32_t obj = (uint32_t)__builtin_amdgcn_ds_bpermute(k << 2, (int)ref);
+                if (s < kGridBatch * 3 && (uint32_t)k < n) {
+                    if (obj < p.n_sph) {
+                        if (part == 0) batch[s] = p.sph_filter[obj];
+                    } else {
+                        batch[s] = p.tri_filter[(size_t)(obj - p.n_sph) * 3 + part];
+                    }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t obj = (uint32_t)__builtin_amdgcn_readlane((int)ref, (int)k);
+                if (obj < p.n_sph)
+                    survivor_sphere<PROJ>(p, obj, batch[k * 3], st, n_exact, recorded);
+                else
+                    survivor_triangle<PROJ>(p, obj - p.n_sph, batch[k * 3 + 0], batch[k * 3 + 1], batch[k * 3 + 2], st,
+                                            n_exact, recorded);
+            }
+            // the next batch overwrites the records only after the reads above
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (uint32_t k = 0; k < n; ++k) {
-            const uint32_t obj = (uint32_t)__builtin_amdgcn_readlane((int)ref, (int)k);
-            if (obj < p.n_sph)
-                survivor_sphere<PROJ>(p, obj, batch[k * 3], st, n_exact, recorded);
-            else
-                survivor_triangle<PROJ>(p, obj - p.n_sph, batch[k * 3 + 0], batch[k * 3 + 1], batch[k * 3 + 2], st,
-                                        n_exact, recorded);
-        }
-        // the next batch overwrites the records only after the reads above
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (recorded && lane == 0) s_hit[t] = 1u;
     }
-
     if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
-    if (!recorded)
+    __syncthreads();
+
+    if (!own_active) return;
+    const uint32_t bg = shade_pixel<PROJ>(p, 0u, 0u, -1.0f, -1);       // the colour of a miss
+    if (begin == end || s_hit[wave] == 0u)      // nothing listed for this cell, or nothing hit
         tile_background(p, bg, x0, lr0, t_out, id_out, pitch);
     else if (p.fuse_shade)
-        tile_end_shaded<PROJ>(p, st, bg, wave_x0, wave_lr0, x0, lr0, t_out, id_out, pitch);
+        tile_end_shaded<PROJ>(p, own, bg, wave_x0, wave_lr0, x0, lr0, t_out, id_out, pitch);
     else
-        tile_end<PROJ, false>(p, st, x0, lr0, t_out, id_out, pitch);
+        tile_end<PROJ, false>(p, own, x0, lr0, t_out, id_out, pitch);
 }
 
 // ---------------------------------------------------------------------------
