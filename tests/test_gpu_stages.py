@@ -105,10 +105,29 @@ def test_stage_intersect_bounds_and_untouched_bytes(gpu_ctx, mrt, oracle):
     pre = np.zeros(len(rays), mrt.CL_DTYPES["intersect"])
     pre["location"][:] = 7.0
     pre["dummy2"][:] = 9.0
+    # bytes no named field covers (dummy3 at 41..56, dummy1 at 59) and lane 3 of the float3 fields
+    raw = pre.view(np.uint8).reshape(len(pre), 80)
+    raw[:, 41:57] = 0xA5
+    raw[:, 59] = 0x5A
+    raw[:, 12:16] = 0xC3
+    raw[:, 28:32] = 0x3C
+    raw[:, 76:80] = 0x99
+    def raw_copy(a):
+        # ndarray.copy() of a structured array copies field by field and leaves the gaps between
+        # fields undefined; a copy of the bytes keeps them
+        return a.view(np.uint8).copy().view(a.dtype)
+
     for hi, lo in [(np.finfo(np.float32).max, 0.0), (3.0, 0.0), (100.0, 2.0), (1.0, 0.0)]:
-        g = gpu_ctx.stage_intersect(objs, rays, hi, lo, out=pre.copy())
-        o, _ = oracle.stage_intersect(objs, rays, hi, lo, out=pre.copy())
+        g = gpu_ctx.stage_intersect(objs, rays, hi, lo, out=raw_copy(pre))
+        o, _ = oracle.stage_intersect(objs, rays, hi, lo, out=raw_copy(pre))
         same_records(g, o)
+        # kernel.cl:361-377 assigns named fields only: everything else keeps the caller's bytes, on
+        # hits and on misses, so the whole 80-byte records agree too
+        graw, oraw = (a.view(np.uint8).reshape(len(a), 80) for a in (g, o))
+        for lo_b, hi_b in ((41, 57), (59, 60), (12, 16), (28, 32), (76, 80)):
+            assert np.array_equal(graw[:, lo_b:hi_b], raw[:, lo_b:hi_b]), (lo_b, "library")
+            assert np.array_equal(oraw[:, lo_b:hi_b], raw[:, lo_b:hi_b]), (lo_b, "oracle")
+        assert np.array_equal(graw, oraw)
     miss = g["intersects"] == 0
     assert miss.any() and (g["location"][miss] == 7.0).all()
 
