@@ -308,8 +308,7 @@ enum {
     /* Uniform grid over the image with cells of 32x32 pixels, built on the GPU
      * for every view (mrt_accel_set_scene / _set_camera: bin count, exclusive
      * scan, fill): each cell lists the objects whose conservative screen-space
-     * region touches it, and a frame walks one list per cell.  The build reads
-     * one word back, so those two calls wait for the GPU. */
+     * region touches it, and a frame walks one list per cell. */
     MRT_ACCEL_GRID = 0,
     /* No structure: every frame tests every object against every 32x32 tile
      * (64 objects per wave instruction) and only the survivors per pixel. */
@@ -338,8 +337,10 @@ void mrt_accel_destroy(mrt_accel *a);
 /* Text of the last error on a (of the last failed mrt_accel_create when a is NULL). */
 const char *mrt_accel_last_error(const mrt_accel *a);
 uint32_t mrt_accel_method(const mrt_accel *a);
-/* As mrt_set_scene / mrt_set_camera; GRID also (re)builds the grid for the view
- * and fails with MRT_ERR_TOO_LARGE beyond 2^28 references. */
+/* As mrt_set_scene / mrt_set_camera; GRID also (re)builds the grid for the view,
+ * on the GPU.  mrt_accel_set_camera does not wait for it: beyond 2^28 references
+ * mrt_accel_set_scene fails with MRT_ERR_TOO_LARGE at once, after
+ * mrt_accel_set_camera the first frame of that view does. */
 int mrt_accel_set_scene(mrt_accel *a, const mrt_scene *scene);
 int mrt_accel_set_camera(mrt_accel *a, const mrt_camera *camera);
 /* As mrt_render_rgba8 / mrt_render_debug / mrt_render_bands_device.  Interleaved
