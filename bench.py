@@ -274,33 +274,54 @@ def set_camera_cost(env, sc, reps=50):
 def native_multi_gpu(env, mkscene, world):
     """The library's own single-process multi-GPU path (mrt_multi_*: one context and stream per
     GPU, bands gathered to GPU 0 with RCCL, band-wise copies to the host image) through the
-    mrraytracer binary, as a child process of rank 0 while the other ranks wait: the 7680x4320
-    teatime frame and the 16384^2 soup on `world` GPUs.  Frame time includes the copy of the
-    image to page-locked host memory (unlike `value`).  A failure is reported, not raised."""
+    mrraytracer binary, as a child process of rank 0 while the other ranks wait on the host: the
+    7680x4320 teatime frame and the 16384^2 soup on `world` GPUs.  Frame time includes the copy of
+    the image to page-locked host memory (unlike `value`).  A failure is reported, not raised; if
+    a run fails or times out with the default transport the next one copies through the host."""
     import subprocess
     cli = ROOT / "opencl-raytracing_amd" / "mrraytracer"
     res = {}
+    gather = None                                       # the library's choice: RCCL between distinct GPUs
     with tempfile.TemporaryDirectory() as d:
         for key, text in (("teatime8k", mkscene.teatime(7680, 4320)), ("soup16k", mkscene.soup(16384, 16384))):
             scene, png = Path(d) / f"{key}.json", Path(d) / f"{key}.png"
             scene.write_text(text)
             child_env = dict(os.environ, MRT_GPUS=str(world), MRT_STATS="1", MRT_REPEAT="5")
+            if gather:
+                child_env["MRT_GATHER"] = gather
             if env.rehearsal:
                 child_env["MRT_GPU_LIST"] = ",".join(["0"] * world)
             elif world == 1:
                 child_env["MRT_GPU_LIST"] = "0"          # one rank through the same multi-GPU code
             try:
                 r = subprocess.run([str(cli), str(scene), str(png)], capture_output=True, text=True,
-                                   env=child_env, timeout=240)
+                                   env=child_env, timeout=120)
                 if r.returncode != 0:
                     res[key] = {"error": r.stderr.strip()[-300:]}
+                    gather = "host"
                     continue
                 st = json.loads(r.stderr.strip().splitlines()[-1])
                 res[key] = {k: st[k] for k in ("n_gpus", "gather", "note", "render_ms_max", "render_ms_sum",
                                                "best_frame_ms", "mrays_per_s", "png_ms", "total_ms")}
             except Exception as e:            # noqa: BLE001 -- a report, never a crash of the benchmark
                 res[key] = {"error": repr(e)[:300]}
+                gather = "host"
     return res
+
+
+def host_side_handshake(env, key):
+    """Rank 0 announces `key`, the other ranks wait for it through the process group's key-value
+    store, i.e. on the host: their GPUs stay idle meanwhile (a collective barrier would spin on
+    them).  Best effort: without the store the caller's collective barrier does the waiting."""
+    from datetime import timedelta
+    try:
+        store = env.dist.distributed_c10d._get_default_store()
+        if env.rank == 0:
+            store.set(key, "1")
+        else:
+            store.wait([key], timedelta(seconds=600))
+    except Exception:                         # noqa: BLE001
+        pass
 
 
 def host_frame(env, job, total_rays):
@@ -460,14 +481,19 @@ def main():
                     out[f"{key}_ms_per_frame"] = sec[name]["ms_per_frame"]
                     out[f"{key}_mrays_per_s"] = sec[name]["mrays_per_s"]
                     out[f"{key}_scaling"] = "strong"
-    if rank == 0 and not args.no_secondary:
-        nat = native_multi_gpu(env, mkscene, world)
-        out["native_multi_gpu"] = nat
-        for key, e in nat.items():
-            if "best_frame_ms" in e:
-                out[f"native_{key}_frame_ms"] = e["best_frame_ms"]
-                out[f"native_{key}_mrays_per_s"] = e["mrays_per_s"]
-                out[f"native_{key}_gather"] = e["gather"]
+    if not args.no_secondary:
+        if env.use_dist:
+            torch.cuda.synchronize(env.dev)
+        if rank == 0:
+            nat = native_multi_gpu(env, mkscene, world)
+            out["native_multi_gpu"] = nat
+            for key, e in nat.items():
+                if "best_frame_ms" in e:
+                    out[f"native_{key}_frame_ms"] = e["best_frame_ms"]
+                    out[f"native_{key}_mrays_per_s"] = e["mrays_per_s"]
+                    out[f"native_{key}_gather"] = e["gather"]
+        if env.use_dist:
+            host_side_handshake(env, "native_multi_gpu_done")
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sc)

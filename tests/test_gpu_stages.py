@@ -129,7 +129,7 @@ def test_stage_intersect_bounds_and_untouched_bytes(gpu_ctx, mrt, oracle):
             assert np.array_equal(oraw[:, lo_b:hi_b], raw[:, lo_b:hi_b]), (lo_b, "oracle")
         assert np.array_equal(graw, oraw)
     miss = g["intersects"] == 0
-    assert miss.any() and (g["location"][miss] == 7.0).all()
+    assert miss.any() and (g["location"][miss][:, :3] == 7.0).all()
 
 
 def test_stage_zero_elements_and_errors(gpu_ctx, mrt):

@@ -33,4 +33,6 @@ run_pmc lds SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_L
 run_pmc fetch FETCH_SIZE
 run_pmc write WRITE_SIZE
 run_pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
+# the accelerated entry points (grid build + grid / tile-cull / block-reject frames), kernel trace only
+step trace_accel timeout -k 10 240 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace_accel" -o trace -- python3 $ROOT/tools/time_accel.py teatime4k soup16k
 echo "all passes done"

@@ -16,6 +16,9 @@ def main(src, dst):
     src, dst = Path(src), Path(dst)
     dst.mkdir(parents=True, exist_ok=True)
     shutil.copy(src / "trace" / "trace_kernel_stats.csv", dst / "teatime4k_kernel_stats.csv")
+    accel = src / "trace_accel" / "trace_kernel_stats.csv"
+    if accel.is_file():            # tools/time_accel.py teatime4k soup16k: the mrt_accel_* kernels
+        shutil.copy(accel, dst / "accel_kernel_stats.csv")
     out = {}
     for d in sorted(src.glob("pmc_*")):
         f = d / "pmc_counter_collection.csv"
