@@ -1145,22 +1145,34 @@ __global__ void prep_full_records(const RenderParams p, float4* __restrict__ rec
     else if (sign_src < 0.0f) { sg = -1.0f; slot = p.n_tri - 1u - atomicAdd(&counts[1], 1u); }
     else return;
     if (p_all < 1e36 && ma < 1e36) {               // false for NaN too
-        r0.w = sg * float_up(mb);
-        r2.w = sg * float_up(mg);
+        // Records of the s = -1 group carry s2 and s1 (pinhole) or s2 x d, s1 and s1 x s2
+        // (orthographic) negated: every quantity the kernel forms is then s times the
+        // determinant it stands for, and one verdict -- "none of them negative" -- serves both
+        // groups.  Negation is exact and rounding is symmetric, so the margins are unaffected.
+        if (sg < 0.0f) {
+            if (PROJ == MRT_PROJ_PERSP) {
+                r0.x = -r0.x; r0.y = -r0.y; r0.z = -r0.z;      // s2
+            } else {
+                r0.x = -r0.x; r0.y = -r0.y; r0.z = -r0.z;      // s2 x d
+                r2.x = -r2.x; r2.y = -r2.y; r2.z = -r2.z;      // s1
+            }
+            r3.x = -r3.x; r3.y = -r3.y; r3.z = -r3.z;          // s1 (pinhole), s1 x s2 (orthographic)
+        }
+        r0.w = float_up(mb);
+        r2.w = float_up(mg);
         if (PROJ == MRT_PROJ_PERSP) {
-            r1.w = sg * float_up(ma);
+            r1.w = float_up(ma);
         } else {
-            // D + s Ma has the sign s; rounded away from zero
-            r1.w = sg * float_up(fabs((double)r1.w) + ma);
-            r3.w = sg * float_up(mt);
+            r1.w = float_up(fabs((double)r1.w) + ma);          // s D + Ma, rounded up
+            r3.w = float_up(mt);
         }
     } else {
         // The margins cannot be bounded: a record every pixel passes (all products zero, so
-        // Nb = Ng = s, W = 3 s or 2 s, Nt = s); the exact arithmetic decides every pair.
-        r0 = make_float4(0.f, 0.f, 0.f, sg);
-        r1 = make_float4(0.f, 0.f, 0.f, 4.0f * sg);
-        r2 = make_float4(0.f, 0.f, 0.f, sg);
-        r3 = make_float4(0.f, 0.f, 0.f, sg);
+        // Nb = Ng = 1, W = 3 or 2, Nt = 1); the exact arithmetic decides every pair.
+        r0 = make_float4(0.f, 0.f, 0.f, 1.0f);
+        r1 = make_float4(0.f, 0.f, 0.f, 4.0f);
+        r2 = make_float4(0.f, 0.f, 0.f, 1.0f);
+        r3 = make_float4(0.f, 0.f, 0.f, 1.0f);
     }
     rec[(size_t)slot * kFullRecFloat4 + 0] = r0;
     rec[(size_t)slot * kFullRecFloat4 + 1] = r1;
@@ -1261,8 +1273,7 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
     }
 
     // ---- triangles: object ids n_sph .. n_sph+n_tri-1, one sign group after the other ----
-    auto sign_group = [&](auto pos_tag, uint32_t first, uint32_t n) {
-        constexpr bool POS = decltype(pos_tag)::value;
+    auto sign_group = [&](uint32_t first, uint32_t n) {
         for (uint32_t base = 0; base < n; base += kChunkTris) {
             __syncthreads();
             // the buffer has a chunk of slack beyond the last record
@@ -1278,7 +1289,12 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                 const float4 q1 = s_rec[g * kFullRecFloat4 + 1];
                 const float4 q2 = s_rec[g * kFullRecFloat4 + 2];
                 const float4 q3 = s_rec[g * kFullRecFloat4 + 3];
-                float acc = POS ? -__builtin_inff() : __builtin_inff();
+                // The verdict works on sign bits (v_or3_b32 + v_and_b32 issue faster than
+                // v_min3_f32 + v_max_f32): a pair stays a candidate when none of its quantities
+                // has the sign bit set, and `neg` keeps the sign bit only while every pixel of the
+                // lane has been ruled out.  A quantity that could belong to an accepted pair is
+                // at least half its (positive) margin, so -0 never stands for "not negative".
+                uint32_t neg = 0x80000000u;
                 if (PROJ == MRT_PROJ_PERSP) {
                     const F3 s2 = mk3(q0.x, q0.y, q0.z), sol = mk3(q1.x, q1.y, q1.z);
                     const F3 e = mk3(q2.x, q2.y, q2.z), s1 = mk3(q3.x, q3.y, q3.z);
@@ -1290,8 +1306,7 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                         const float aa = dot_fused(e, c, q1.w);
                         const float ng = dot_fused(s1, kk, q2.w);
                         const float w = aa - ng;
-                        if (POS) acc = __builtin_fmaxf(acc, __builtin_fminf(__builtin_fminf(nb, ng), w));
-                        else acc = __builtin_fminf(acc, __builtin_fmaxf(__builtin_fmaxf(nb, ng), w));
+                        neg &= __float_as_uint(nb) | __float_as_uint(ng) | __float_as_uint(w);
                     }
                 } else {
                     const F3 c = mk3(q0.x, q0.y, q0.z), a = mk3(q1.x, q1.y, q1.z);
@@ -1304,12 +1319,11 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                         const float ng = dot_fused(s1, kk, q2.w);
                         const float nt = dot_fused(sol, nrm, q3.w);
                         const float w = (q1.w - nb) - ng;
-                        if (POS) acc = __builtin_fmaxf(acc, __builtin_fminf(__builtin_fminf(__builtin_fminf(nb, ng), w), nt));
-                        else acc = __builtin_fminf(acc, __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nb, ng), w), nt));
+                        neg &= __float_as_uint(nb) | __float_as_uint(ng) | __float_as_uint(w) | __float_as_uint(nt);
                     }
                 }
-                // not "acc < 0": an acc that is NaN (non-finite rays) may go either way, no such pair is a hit
-                const bool cand = POS ? (acc >= 0.0f) : (acc <= 0.0f);
+                // a quantity that is NaN (non-finite rays) may go either way, no such pair is a hit
+                const bool cand = neg == 0u;
                 if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
                 if (cand) {
                     const uint32_t ti = __builtin_amdgcn_readfirstlane(s_ids[g]);
@@ -1336,8 +1350,8 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
         }
     };
     const uint32_t n_pos = class_counts[0], n_neg = class_counts[1];
-    sign_group(std::true_type{}, 0u, n_pos);
-    sign_group(std::false_type{}, p.n_tri - n_neg, n_neg);
+    sign_group(0u, n_pos);
+    sign_group(p.n_tri - n_neg, n_neg);
 
     if (wave_active) {
 #pragma unroll
