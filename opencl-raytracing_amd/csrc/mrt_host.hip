@@ -333,7 +333,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     if (p.exact_counter) HIP_TRY(ctx, hipMemsetAsync(p.exact_counter, 0, sizeof(unsigned long long), stream));
 
     const dim3 tgrid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY);
-    const dim3 fgrid(pitch / mrt::kBlockTileX, prow / 32);      // full_trace_kernel: blocks of 64 x 32 pixels
+    const dim3 fgrid(pitch / mrt::kBlockTileX, prow / mrt::kFullBlockH);      // full_trace_kernel: blocks of 64 x 32 pixels
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
     // trace_kernel and full_trace_kernel shade their own pixels in the epilogue (one launch per
     // frame); 16-byte stores need rows and buffer aligned to four pixels.  The tile cull runs at

@@ -1008,9 +1008,6 @@ __global__ __launch_bounds__(kBlockThreads) void grid_trace_kernel(const RenderP
 // in registers.  Records (4 x float4 per triangle, made by prep_full_records)
 // are staged through LDS in chunks of 256 triangles (16 KiB).
 // ---------------------------------------------------------------------------
-constexpr int kFullPxX = 4, kFullPxY = 2, kFullSlots = kFullPxX * kFullPxY;
-constexpr int kFullWaveH = 8 * kFullPxY;          // 16 rows per wave
-constexpr int kFullBlockH = 2 * kFullWaveH;       // 32 rows per block
 constexpr int kFullChunkFloat4 = kChunkTris * kFullRecFloat4;
 
 namespace {
@@ -1289,8 +1286,9 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                 const float4 q1 = s_rec[g * kFullRecFloat4 + 1];
                 const float4 q2 = s_rec[g * kFullRecFloat4 + 2];
                 const float4 q3 = s_rec[g * kFullRecFloat4 + 3];
-                // The verdict works on sign bits (v_or3_b32 + v_and_b32 issue faster than
-                // v_min3_f32 + v_max_f32): a pair stays a candidate when none of its quantities
+                // The verdict works on sign bits (v_or3_b32 per pixel and an and-tree over the lane's
+                // pixels; v_min3_f32 + v_max_f32 per pixel took the same time, with two code paths
+                // by sign group): a pair stays a candidate when none of its quantities
                 // has the sign bit set, and `neg` keeps the sign bit only while every pixel of the
                 // lane has been ruled out.  A quantity that could belong to an accepted pair is
                 // at least half its (positive) margin, so -0 never stands for "not negative".

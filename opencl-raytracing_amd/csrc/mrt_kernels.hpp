@@ -26,6 +26,14 @@ constexpr int kBlockTileY = kWaveTile * kBlockWavesY;             // 64
 constexpr int kChunkTris = 256;
 constexpr int kChunkFloat4 = kChunkTris * 3;
 constexpr int kFullRecFloat4 = 4;          // float4 per triangle record of full_trace_kernel
+// full_trace_kernel: a lane owns kFullPxX x kFullPxY pixels, a wave 8 x 8 lanes, a block 2 x 2 waves.
+#ifndef MRT_FULL_PX_Y
+#define MRT_FULL_PX_Y 2
+#endif
+constexpr int kFullPxX = 4, kFullPxY = MRT_FULL_PX_Y, kFullSlots = kFullPxX * kFullPxY;
+constexpr int kFullWaveH = 8 * kFullPxY;          // 16 rows per wave
+constexpr int kFullBlockH = 2 * kFullWaveH;       // 32 rows per block
+static_assert(kBlockTileY % kFullBlockH == 0, "the padded planes are whole full_trace_kernel blocks");
 #ifndef MRT_GROUP_TRIS
 #define MRT_GROUP_TRIS 4
 #endif
