@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 3
+#define MRT_ABI_VERSION 4
 
 typedef enum mrt_status {
     MRT_OK = 0,
@@ -118,7 +118,15 @@ enum {
      * order; only the divisions and the square root wait until the numerators
      * cannot already fail a range test.  Same pixels out.  Takes precedence
      * over the other flags. */
-    MRT_FLAG_FULL_TEST = 1u << 5
+    MRT_FLAG_FULL_TEST = 1u << 5,
+    /* The default kernel exists in two shapes: a lane owns 4x4 pixels (32x32
+     * pixel wave tiles) or 8x4 (64x32 tiles, 10 % fewer instructions per
+     * (pixel, primitive) pair, four times fewer tiles).  The library takes 8x4
+     * for frames -- a rank's rows of one -- of at least 4 Mpixel; these two
+     * flags force one shape whatever the size (measurement and test aid; same
+     * pixels out).  Both set: MRT_ERR_INVALID. */
+    MRT_FLAG_TRACE_NARROW = 1u << 6,
+    MRT_FLAG_TRACE_WIDE = 1u << 7
 };
 
 typedef struct mrt_stats {
@@ -142,7 +150,8 @@ enum {
     MRT_KERNEL_TRACE_BLOCK = 1,   /* ... preceded by the 4x4 block reject                 */
     MRT_KERNEL_CULL = 2,          /* 32x32 tile cull                                      */
     MRT_KERNEL_FULL = 3,          /* a 3x3 solve for every pair (MRT_FLAG_FULL_TEST)      */
-    MRT_KERNEL_GRID = 4           /* per-tile primitive lists of the screen-space grid    */
+    MRT_KERNEL_GRID = 4,          /* per-tile primitive lists of the screen-space grid    */
+    MRT_KERNEL_TRACE_WIDE = 5     /* the default funnel, 8x4 pixels per lane (large frames) */
 };
 
 typedef struct mrt_ctx mrt_ctx;

@@ -23,7 +23,7 @@
 #include <vector>
 
 namespace mrt {
-template <int PROJ, bool BLOCK_REJECT>
+template <int PROJ, bool BLOCK_REJECT, int LX, int LY>
 __global__ void trace_kernel(const RenderParams p, unsigned long long* key_plane, float* t_out, int32_t* id_out,
                              uint32_t pitch);
 template <int PROJ>
@@ -128,6 +128,7 @@ struct mrt_ctx {
     // The last frame enqueued: which kernel it ran, and an event behind it so that a frame on
     // another stream can be ordered after it (the working planes above are shared by all frames).
     uint32_t last_kernel = MRT_KERNEL_TRACE, last_slices = 1;
+    uint32_t last_pitch = 0;                 // pitch of the (t, id) planes the last frame wrote
     hipEvent_t frame_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool frame_pending = false;
@@ -220,7 +221,7 @@ int ensure_keys(mrt_ctx* ctx, size_t elems) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_key, elems * sizeof(unsigned long long)));
     ctx->key_elems = elems;
     ctx->keys_clean = false;
-    const size_t tiles = elems / (mrt::kWaveTile * mrt::kWaveTile);
+    const size_t tiles = elems / (mrt::TraceNarrow::tile_x * mrt::TraceNarrow::tile_y);      // the smaller of the two tile shapes
     if (tiles > ctx->tile_flag_elems) {
         if (ctx->d_tile_flags) { (void)hipFree(ctx->d_tile_flags); ctx->d_tile_flags = nullptr; }
         ctx->tile_flag_elems = 0;
@@ -281,8 +282,18 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         }
         return MRT_OK;
     }
-    const uint32_t pitch = round_up(p.xres, mrt::kBlockTileX);
-    const uint32_t prow = round_up(p.local_rows, mrt::kBlockTileY);
+    // trace_kernel's lane block: 8x4 pixels (64x32 wave tiles) for frames of at least 4 Mpixel,
+    // 4x4 (32x32 tiles) below, where four times more tiles matter more than 10 % fewer
+    // instructions; MRT_FLAG_TRACE_NARROW / _WIDE override.  The block reject is 4x4 only.
+    bool wide = (uint64_t)p.xres * p.local_rows >= (4u << 20);
+    if (ctx->flags & MRT_FLAG_TRACE_NARROW) wide = false;
+    if (ctx->flags & MRT_FLAG_TRACE_WIDE) wide = true;
+    if (ctx->flags & (MRT_IFLAG_BLOCK_REJECT | MRT_IFLAG_SCREEN_CULL | MRT_FLAG_FULL_TEST)) wide = false;
+    const uint32_t block_x = wide ? mrt::TraceWide::block_x : mrt::TraceNarrow::block_x;
+    const uint32_t block_y = wide ? mrt::TraceWide::block_y : mrt::TraceNarrow::block_y;
+    const uint32_t tile_x = block_x / mrt::kBlockWavesX, tile_y = block_y / mrt::kBlockWavesY;
+    const uint32_t pitch = round_up(p.xres, block_x);
+    const uint32_t prow = round_up(p.local_rows, block_y);
     const size_t plane_elems = (size_t)pitch * prow;
 
     // A single band (one rank, or bands at least as tall as the image) is a run of consecutive
@@ -313,7 +324,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         } else {
             if (plane_elems > planes.key_capacity)
                 return fail(ctx, MRT_ERR_TOO_LARGE,
-                            "this rank's rows, padded to 64x64 tiles, need " + std::to_string(plane_elems) +
+                            "this rank's rows, padded to whole block tiles, need " + std::to_string(plane_elems) +
                                 " closest-hit keys; the fixed array holds " + std::to_string(planes.key_capacity));
             d_key = planes.key;
         }
@@ -332,7 +343,8 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->records_ready, 0));
     if (p.exact_counter) HIP_TRY(ctx, hipMemsetAsync(p.exact_counter, 0, sizeof(unsigned long long), stream));
 
-    const dim3 tgrid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY);
+    const dim3 tgrid(pitch / block_x, prow / block_y);
+    const dim3 cgrid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY);      // cull_trace_kernel: 64 x 64
     const dim3 fgrid(pitch / mrt::kBlockTileX, prow / mrt::kFullBlockH);      // full_trace_kernel: blocks of 64 x 32 pixels
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
     // trace_kernel and full_trace_kernel shade their own pixels in the epilogue (one launch per
@@ -342,26 +354,32 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     p.fuse_shade = cull ? 0u : fused;
     // trace_kernel takes the triangle list in slices, one grid layer each; the (t, id) keys merge
     // them.  A frame with few tiles needs that to fill the GPU at all (a wave alone on its SIMD
-    // issues at a fraction of the rate six reach together); a 4K frame (8160 tiles) still gains
-    // 7 % from 16 times more, 16 times shorter waves, because the machine spends less of the frame
-    // filling up and draining.  Target: about 128 K waves per launch; whole LDS chunks per slice.
+    // issues at a fraction of the rate six reach together); a 4K frame still gains from many
+    // times more, shorter waves, because the machine spends less of the frame filling up and
+    // draining.  Target: about 128 K waves per launch.  A slice is a whole number of circle
+    // groups, at least kMinSliceTris triangles (below that the per-wave set-up dominates).
     p.prim_slices = 1;
     p.slice_tris = p.n_tri_padded;
     if (!full && !cull) {
+        constexpr uint32_t kMinSliceTris = 32;
+        static_assert(kMinSliceTris % mrt::kGroupCircle == 0 && mrt::kChunkTris % kMinSliceTris == 0, "slices are whole circle groups");
         const uint32_t waves = tgrid.x * tgrid.y * (mrt::kBlockThreads / 64);
-        const uint32_t chunks = p.n_tri_padded / mrt::kChunkTris;
+        const uint32_t units = p.n_tri_padded / kMinSliceTris;
         const char* force = std::getenv("MRT_FORCE_SLICES");          // tuning aid
         uint32_t want = force ? (uint32_t)std::atoi(force) : (131072u + waves - 1) / waves;
-        if (want > chunks) want = chunks;
+        if (want > units) want = units;
         if (want > 1) {
-            const uint32_t per = (chunks + want - 1) / want;
-            p.slice_tris = per * mrt::kChunkTris;
-            p.prim_slices = (chunks + per - 1) / per;
+            const uint32_t per = (units + want - 1) / want;
+            p.slice_tris = per * kMinSliceTris;
+            p.prim_slices = (units + per - 1) / per;
         }
     }
     const dim3 zgrid(tgrid.x, tgrid.y, p.prim_slices);
     p.tile_flags = nullptr;
-    p.tiles_x = pitch / mrt::kWaveTile;
+    p.tiles_x = pitch / tile_x;
+    p.tile_x_log2 = wide ? 6u : 5u;
+    p.tile_y_log2 = 5u;
+    static_assert(mrt::TraceWide::tile_x == 64 && mrt::TraceNarrow::tile_x == 32 && mrt::TraceWide::tile_y == 32 && mrt::TraceNarrow::tile_y == 32, "tile sizes as shifts");
     const bool keeps_keys_clean = p.prim_slices > 1 && planes.own;
     if (keeps_keys_clean) {
         // The ctx's own key plane stays all "no hit" from frame to frame: shade_keys_kernel puts
@@ -371,7 +389,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
             HIP_TRY(ctx, hipMemsetAsync(d_key, 0xFF, ctx->key_elems * sizeof(unsigned long long), stream));
         ctx->keys_clean = false;               // until this frame's shade_keys_kernel is enqueued
         p.tile_flags = ctx->d_tile_flags;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_flags, 0, plane_elems / (mrt::kWaveTile * mrt::kWaveTile) * sizeof(uint32_t), stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_flags, 0, plane_elems / ((size_t)tile_x * tile_y) * sizeof(uint32_t), stream));
     } else if (p.prim_slices > 1) {
         HIP_TRY(ctx, hipMemsetAsync(d_key, 0xFF, plane_elems * sizeof(unsigned long long), stream));
     } else if (d_key != nullptr && planes.own) {
@@ -388,22 +406,28 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
                            (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, d_t, d_id, pitch);
     } else if (cull && persp) {
         kernel = MRT_KERNEL_CULL;
-        hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_PERSP>), tgrid, tb, 0, stream, p, d_t, d_id, pitch);
+        hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_PERSP>), cgrid, tb, 0, stream, p, d_t, d_id, pitch);
     } else if (cull) {
         kernel = MRT_KERNEL_CULL;
-        hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_ORTHO>), tgrid, tb, 0, stream, p, d_t, d_id, pitch);
+        hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_ORTHO>), cgrid, tb, 0, stream, p, d_t, d_id, pitch);
     } else if (persp && block) {
         kernel = MRT_KERNEL_TRACE_BLOCK;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+    } else if (persp && wide) {
+        kernel = MRT_KERNEL_TRACE_WIDE;
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, 8, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else if (persp) {
         kernel = MRT_KERNEL_TRACE;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else if (block) {
         kernel = MRT_KERNEL_TRACE_BLOCK;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+    } else if (wide) {
+        kernel = MRT_KERNEL_TRACE_WIDE;
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, 8, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else {
         kernel = MRT_KERNEL_TRACE;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));
@@ -427,6 +451,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], stream));
     ctx->last_kernel = kernel;
     ctx->last_slices = p.prim_slices;
+    ctx->last_pitch = pitch;
     if (planes.own) {
         HIP_TRY(ctx, hipEventRecord(ctx->frame_done, stream));
         ctx->last_stream = stream;
@@ -479,6 +504,8 @@ int mrt_create(const mrt_config* cfg, mrt_ctx** out) {
     if (cfg && (cfg->flags & MRT_IFLAG_MASK))
         return fail(nullptr, MRT_ERR_INVALID,
                     "flag bits 2 and 4 are reserved: screen-space culling is behind mrt_accel_create, not a flag of the brute-force context");
+    if (cfg && (cfg->flags & MRT_FLAG_TRACE_NARROW) && (cfg->flags & MRT_FLAG_TRACE_WIDE))
+        return fail(nullptr, MRT_ERR_INVALID, "MRT_FLAG_TRACE_NARROW and MRT_FLAG_TRACE_WIDE exclude each other");
     return mrt_create_internal_(cfg, out);
 }
 
@@ -837,7 +864,7 @@ int mrt_render_debug(mrt_ctx* ctx, uint8_t* host_out, int32_t* ids, float* t, mr
     (void)hipEventRecord(d0, ctx->stream);
     hipError_t e = hipSuccess;
     if (host_out) e = hipMemcpyAsync(host_out, ctx->d_out, npx * 4, hipMemcpyDeviceToHost, ctx->stream);
-    const uint32_t pitch = round_up(xres, mrt::kBlockTileX);
+    const uint32_t pitch = ctx->last_pitch;                   // as launch_frame padded the planes
     if (e == hipSuccess && ids)
         e = hipMemcpy2DAsync(ids, (size_t)xres * 4, ctx->d_id, (size_t)pitch * 4, (size_t)xres * 4, yres, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && t)

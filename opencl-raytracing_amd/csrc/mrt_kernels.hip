@@ -52,6 +52,7 @@ __device__ __forceinline__ float in_vgpr(float x) {
 
 // Image row of packed local row lr for this rank (interleaved bands).
 __device__ __forceinline__ uint32_t image_row(const RenderParams& p, uint32_t lr) {
+    if (p.world == 1) return lr;              // one rank: its rows are the image's (wave-uniform branch)
     uint32_t band = lr / p.band_rows;
     uint32_t within = lr - band * p.band_rows;
     return (band * p.world + p.rank) * p.band_rows + within;
@@ -72,6 +73,12 @@ __device__ __forceinline__ void stage_chunk(float4* dst, const float4* __restric
 #pragma unroll
     for (int k = 0; k < kChunkFloat4 / kBlockThreads; ++k)
         dst[tid + k * kBlockThreads] = src[tid + k * kBlockThreads];
+}
+// ... of its first n float4 only (the last chunk of a slice that is not a whole number of chunks).
+__device__ __forceinline__ void stage_chunk(float4* dst, const float4* __restrict__ src, int tid, uint32_t n) {
+#pragma unroll
+    for (int k = 0; k < kChunkFloat4 / kBlockThreads; ++k)
+        if ((uint32_t)(tid + k * kBlockThreads) < n) dst[tid + k * kBlockThreads] = src[tid + k * kBlockThreads];
 }
 
 // The colour of pixel (x, y) given its closest hit (t, object id; id < 0: no hit): rebuilds
@@ -159,11 +166,11 @@ __device__ __forceinline__ void shade_row4(const RenderParams& p, uint32_t x0, u
 // evaluated, which lets the kernels below hand pixels to whichever lane is free.
 constexpr unsigned long long kNoHitKey = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;   // (FLT_MAX, -1)
 
-// The reference arithmetic for one primitive over a list of pixels of the wave's 32x32 tile
-// (entry = 32 * row + column), 64 pixels at a time whichever lane owns them.  tile_ux / tile_uy
+// The reference arithmetic for one primitive over a list of pixels of the wave's tile, TW pixels
+// wide (entry = TW * row + column), 64 pixels at a time whichever lane owns them.  tile_ux / tile_uy
 // are the uv components of the tile's columns and rows; keys points at the tile's first pixel
 // in a key array with `stride` keys per row (LDS or global memory).
-template <int PROJ, bool TRI>
+template <int PROJ, bool TRI, int TW = kWaveTile>
 __device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim, uint32_t total, int lane,
                                            const uint16_t* __restrict__ list, const float* __restrict__ tile_ux,
                                            const float* __restrict__ tile_uy, unsigned long long* __restrict__ keys,
@@ -187,7 +194,7 @@ __device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim,
         if (idx < total) {
             const uint32_t px = list[idx];
             F3 o, d;
-            pixel_ray<PROJ>(p, tile_ux[px & 31u], tile_uy[px >> 5], o, d);
+            pixel_ray<PROJ>(p, tile_ux[px % (uint32_t)TW], tile_uy[px / (uint32_t)TW], o, d);
             float t;
             bool hit, two;
             // Bounds of scene::intersect (gfxraytrace.hpp:812-813); the running bound of the
@@ -195,7 +202,7 @@ __device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim,
             if (TRI) hit = tri_exact(A, B, C, o, d, FLT_MAX, 0.0f, t);
             else hit = sphere_exact(A, radius, o, d, FLT_MAX, 0.0f, t, two);
             if (hit && t > 0.0f && t < FLT_MAX) {
-                atomicMin(&keys[(size_t)(px >> 5) * stride + (px & 31u)],
+                atomicMin(&keys[(size_t)(px / (uint32_t)TW) * stride + (px % (uint32_t)TW)],
                           ((unsigned long long)__float_as_uint(t) << 32) | obj_id);
                 rec = true;
             }
@@ -206,19 +213,20 @@ __device__ __forceinline__ void exact_list(const RenderParams& p, uint32_t prim,
     }
 }
 
-// Lists the pixels of `mask` (bit r = row r/4, column r%4 of the lane's 4x4 block at (bx, by)
-// inside the tile) in `list`; returns how many pixels the whole wave listed.  LDS operations of
+// Lists the pixels of `mask` (bit r = row r/LX, column r%LX of the lane's LX-wide block at
+// (bx, by) inside the tile, TW pixels wide) in `list`; returns how many pixels the whole wave listed.  LDS operations of
 // one wave complete in order and the arrays belong to this wave alone, so wave-level fences are
 // all the synchronisation needed.
-__device__ __forceinline__ uint32_t list_pixels(uint32_t mask, uint32_t bx, uint32_t by, int lane,
+template <int LX = kLanePx, int TW = kWaveTile, typename MASK = uint32_t>
+__device__ __forceinline__ uint32_t list_pixels(MASK mask, uint32_t bx, uint32_t by, int lane,
                                                 uint16_t* __restrict__ list, uint32_t* __restrict__ count) {
-    const uint32_t c = (uint32_t)__builtin_popcount(mask);
+    const uint32_t c = (uint32_t)__builtin_popcountll((unsigned long long)mask);
     uint32_t at = 0;
     if (c) at = atomicAdd(count, c);
     while (mask) {
-        const uint32_t r = (uint32_t)__builtin_ctz(mask);
+        const uint32_t r = (uint32_t)__builtin_ctzll((unsigned long long)mask);
         mask &= mask - 1;
-        list[at++] = (uint16_t)((by + (r >> 2)) * kWaveTile + bx + (r & 3u));
+        list[at++] = (uint16_t)((by + r / (uint32_t)LX) * TW + bx + r % (uint32_t)LX);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -231,34 +239,42 @@ __device__ __forceinline__ uint32_t list_pixels(uint32_t mask, uint32_t bx, uint
 
 }  // namespace
 
-template <int PROJ, bool BLOCK_REJECT>
+template <int PROJ, bool BLOCK_REJECT, int LX, int LY>
 __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace_kernel(const RenderParams p,
                                                              unsigned long long* __restrict__ key_plane,
                                                              float* __restrict__ t_out,
                                                              int32_t* __restrict__ id_out,
                                                              uint32_t pitch) {
+    using Shape = TraceShape<LX, LY>;
+    constexpr int kTrLaneX = Shape::lane_x, kTrLaneY = Shape::lane_y;
+    constexpr int kTrTileX = Shape::tile_x, kTrTileY = Shape::tile_y;
+    constexpr int kTrBlockX = Shape::block_x, kTrBlockY = Shape::block_y;
+    static_assert(!BLOCK_REJECT || (LX == 4 && LY == 4), "the block-origin constants of the records are made for 4x4 blocks");
     __shared__ float4 s_rec[kChunkFloat4];
     __shared__ float4 s_circ[kChunkTris];
     // per wave: the pixels one primitive still has to be tested on, and the tile's uv components
-    __shared__ uint16_t s_list[kBlockThreads / 64][kWaveTile * kWaveTile];
-    __shared__ float s_ux[kBlockThreads / 64][kWaveTile], s_uy[kBlockThreads / 64][kWaveTile];
+    __shared__ uint16_t s_list[kBlockThreads / 64][kTrTileX * kTrTileY];
+    __shared__ float s_ux[kBlockThreads / 64][kTrTileX], s_uy[kBlockThreads / 64][kTrTileY];
+    // one bit per pixel of the lane's block, bit j * kTrLaneX + i = row j, column i
+    using Mask = typename std::conditional<(kTrLaneX * kTrLaneY > 32), unsigned long long, uint32_t>::type;
+    constexpr Mask kAllPixels = (Mask)(~(Mask)0) >> (8 * sizeof(Mask) - kTrLaneX * kTrLaneY);
     __shared__ uint32_t s_count[kBlockThreads / 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint32_t x0 = blockIdx.x * kBlockTileX + (wave & 1) * kWaveTile + (lane & 7) * kLanePx;
-    const uint32_t lr0 = blockIdx.y * kBlockTileY + (wave >> 1) * kWaveTile + (lane >> 3) * kLanePx;
-    // Wave-uniform: does this wave's 32x32 tile touch the image at all?
-    const uint32_t wave_x0 = blockIdx.x * kBlockTileX + (wave & 1) * kWaveTile;
-    const uint32_t wave_lr0 = blockIdx.y * kBlockTileY + (wave >> 1) * kWaveTile;
+    const uint32_t x0 = blockIdx.x * kTrBlockX + (wave & 1) * kTrTileX + (lane & 7) * kTrLaneX;
+    const uint32_t lr0 = blockIdx.y * kTrBlockY + (wave >> 1) * kTrTileY + (lane >> 3) * kTrLaneY;
+    // Wave-uniform: does this wave's tile touch the image at all?
+    const uint32_t wave_x0 = blockIdx.x * kTrBlockX + (wave & 1) * kTrTileX;
+    const uint32_t wave_lr0 = blockIdx.y * kTrBlockY + (wave >> 1) * kTrTileY;
     const bool wave_active = (wave_x0 < p.xres) && (wave_lr0 < p.local_rows);
 
     // Pixel coordinates as floats: all the prefilters need.
     const float xf = (float)x0;
-    float yf[kLanePx];
+    float yf[kTrLaneY];
 #pragma unroll
-    for (int j = 0; j < kLanePx; ++j) {
+    for (int j = 0; j < kTrLaneY; ++j) {
         const uint32_t lr = lr0 + j;
         const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
         yf[j] = (float)image_row(p, lr < last_row ? lr : last_row);
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     // upper bound (gfxraytrace.hpp:813) and "no object".  The planes are padded to whole block
     // tiles, so no bounds checks.  Also the uv components of the tile's 32 columns and 32 rows
     // (gfxraytrace.hpp:850-852: the pixel grid is (x + 1, y + 1)) for the exact step.
-    const uint32_t bx = (lane & 7) * kLanePx, by = (lane >> 3) * kLanePx;
+    const uint32_t bx = (lane & 7) * kTrLaneX, by = (lane >> 3) * kTrLaneY;
     uint16_t* list = s_list[wave];
     float* tile_ux = s_ux[wave];
     float* tile_uy = s_uy[wave];
@@ -282,19 +298,20 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     if (wave_active) {
         if (single_slice) {
 #pragma unroll
-            for (int j = 0; j < kLanePx; ++j) {
+            for (int j = 0; j < kTrLaneY; ++j) {
                 ulonglong2* row = reinterpret_cast<ulonglong2*>(key_plane + (size_t)(lr0 + j) * pitch + x0);
-                row[0] = make_ulonglong2(kNoHitKey, kNoHitKey);
-                row[1] = make_ulonglong2(kNoHitKey, kNoHitKey);
+#pragma unroll
+                for (int i = 0; i < kTrLaneX / 2; ++i) row[i] = make_ulonglong2(kNoHitKey, kNoHitKey);
             }
         }
         const uint32_t last_row = p.local_rows ? p.local_rows - 1 : 0;
-        const uint32_t k = lane & 31;
-        if (lane < 32) {
-            tile_ux[k] = uv_component(p.left, p.right, (float)(wave_x0 + k) + 1.0f, p.xres_f);
-        } else {
-            const uint32_t lr = wave_lr0 + k;
-            tile_uy[k] = uv_component(p.bottom, p.top, (float)image_row(p, lr < last_row ? lr : last_row) + 1.0f, p.yres_f);
+        for (uint32_t k = (uint32_t)lane; k < (uint32_t)(kTrTileX + kTrTileY); k += 64) {
+            if (k < (uint32_t)kTrTileX) {
+                tile_ux[k] = uv_component(p.left, p.right, (float)(wave_x0 + k) + 1.0f, p.xres_f);
+            } else {
+                const uint32_t lr = wave_lr0 + (k - kTrTileX);
+                tile_uy[k - kTrTileX] = uv_component(p.bottom, p.top, (float)image_row(p, lr < last_row ? lr : last_row) + 1.0f, p.yres_f);
+            }
         }
         if (lane == 0) *list_count = 0;
     }
@@ -321,17 +338,17 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
 #pragma unroll
             for (int tt = 0; tt < kGroupSph; ++tt) {
                 const float4 e = s_rec[g + tt];
-                float dvm[kLanePx];
+                float dvm[kTrLaneY];
 #pragma unroll
-                for (int j = 0; j < kLanePx; ++j) {
+                for (int j = 0; j < kTrLaneY; ++j) {
                     const float dv = __builtin_fmaf(yf[j], e.z, e.w);
                     dvm[j] = __builtin_fmaf(dv, dv, -1.0f);
                 }
                 float du = __builtin_fmaf(xf, e.x, e.y);
 #pragma unroll
-                for (int i = 0; i < kLanePx; ++i) {
+                for (int i = 0; i < kTrLaneX; ++i) {
 #pragma unroll
-                    for (int j = 0; j < kLanePx; ++j) acc = __builtin_fminf(acc, __builtin_fmaf(du, du, dvm[j]));
+                    for (int j = 0; j < kTrLaneY; ++j) acc = __builtin_fminf(acc, __builtin_fmaf(du, du, dvm[j]));
                     du += e.x;
                 }
             }
@@ -342,21 +359,21 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                 const uint32_t si = base + g + tt;
                 if (si >= p.n_sph) break;
                 const float4 e = s_rec[g + tt];
-                uint32_t mask = 0;
+                Mask mask = 0;
                 float du = __builtin_fmaf(xf, e.x, e.y);
 #pragma unroll
-                for (int i = 0; i < kLanePx; ++i) {
+                for (int i = 0; i < kTrLaneX; ++i) {
 #pragma unroll
-                    for (int j = 0; j < kLanePx; ++j) {
+                    for (int j = 0; j < kTrLaneY; ++j) {
                         const float dv = __builtin_fmaf(yf[j], e.z, e.w);
-                        if (__builtin_fmaf(du, du, __builtin_fmaf(dv, dv, -1.0f)) <= 0.0f) mask |= 1u << (j * kLanePx + i);
+                        if (__builtin_fmaf(du, du, __builtin_fmaf(dv, dv, -1.0f)) <= 0.0f) mask |= (Mask)1 << (j * kTrLaneX + i);
                     }
                     du += e.x;
                 }
-                if (no_prefilter) mask = 0xFFFFu;
+                if (no_prefilter) mask = kAllPixels;
                 if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
-                const uint32_t total = list_pixels(mask, bx, by, lane, list, list_count);
-                exact_list<PROJ, false>(p, si, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact, recorded);
+                const uint32_t total = list_pixels<kTrLaneX, kTrTileX, Mask>(mask, bx, by, lane, list, list_count);
+                exact_list<PROJ, false, kTrTileX>(p, si, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact, recorded);
             }
         }
     }
@@ -365,19 +382,22 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     // Record: 12 floats (A0,B0,C0,A1 | B1,C1,A2,B2 | C2,-,-,-); edge k passes at
     // pixel (x, y) when A_k*x + B_k*y + C_k >= 0.
     const uint32_t tri_begin = single_slice ? 0u : blockIdx.z * p.slice_tris;
+    // A slice is a whole number of circle groups (the host sees to that), not of chunks.
     const uint32_t tri_end = single_slice ? p.n_tri_padded
                                           : (tri_begin + p.slice_tris < p.n_tri_padded ? tri_begin + p.slice_tris : p.n_tri_padded);
+    const uint32_t tri_stop = tri_end < p.n_tri ? tri_end : p.n_tri;     // the first triangle this wave does not test
     for (uint32_t base = tri_begin; base < tri_end; base += kChunkTris) {
+        const uint32_t staged = tri_end - base < (uint32_t)kChunkTris ? tri_end - base : (uint32_t)kChunkTris;
         __syncthreads();
-        stage_chunk(s_rec, p.tri_filter + (size_t)base * 3, tid);
+        stage_chunk(s_rec, p.tri_filter + (size_t)base * 3, tid, staged * 3);
 #pragma unroll
         for (int k = 0; k < kChunkTris / kBlockThreads; ++k)
-            s_circ[tid + k * kBlockThreads] = p.tri_circle[base + tid + k * kBlockThreads];
+            if ((uint32_t)(tid + k * kBlockThreads) < staged) s_circ[tid + k * kBlockThreads] = p.tri_circle[base + tid + k * kBlockThreads];
         __syncthreads();
         if (!wave_active) continue;
 
         for (int gc = 0; gc < kChunkTris; gc += kGroupCircle) {
-        if (base + gc >= p.n_tri) break;
+        if (base + gc >= tri_stop) break;
         if (use_circle && BLOCK_REJECT) {
             // Opt-in block form of the circle test: the point of this lane's 4x4 block
             // nearest to the centre, per axis, is the centre's coordinate clamped to the
@@ -387,8 +407,8 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
             for (int tt = 0; tt < kGroupCircle; ++tt) {
                 const float4 c = s_circ[gc + tt];
                 const float du0 = xf - c.x, dv0 = yf[0] - c.y;
-                const float du = __builtin_amdgcn_fmed3f(du0, du0 + 3.0f, 0.0f);
-                const float dv = __builtin_amdgcn_fmed3f(dv0, dv0 + 3.0f, 0.0f);
+                const float du = __builtin_amdgcn_fmed3f(du0, du0 + (float)(kTrLaneX - 1), 0.0f);
+                const float dv = __builtin_amdgcn_fmed3f(dv0, dv0 + (float)(kTrLaneY - 1), 0.0f);
                 accc = __builtin_fminf(accc, __builtin_fmaf(du, du, __builtin_fmaf(dv, dv, -c.z)));
             }
             if (__builtin_amdgcn_ballot_w64(accc <= 0.0f) == 0) continue;
@@ -399,24 +419,24 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
 #pragma unroll
             for (int tt = 0; tt < kGroupCircle; ++tt) {
                 const float4 c = s_circ[gc + tt];
-                float dvm[kLanePx];
+                float dvm[kTrLaneY];
 #pragma unroll
-                for (int j = 0; j < kLanePx; ++j) {
+                for (int j = 0; j < kTrLaneY; ++j) {
                     const float dv = yf[j] - c.y;
                     dvm[j] = __builtin_fmaf(dv, dv, -c.z);
                 }
                 const float du0 = xf - c.x;
 #pragma unroll
-                for (int i = 0; i < kLanePx; ++i) {
+                for (int i = 0; i < kTrLaneX; ++i) {
                     const float du = du0 + (float)i;
 #pragma unroll
-                    for (int j = 0; j < kLanePx; ++j) accc = __builtin_fminf(accc, __builtin_fmaf(du, du, dvm[j]));
+                    for (int j = 0; j < kTrLaneY; ++j) accc = __builtin_fminf(accc, __builtin_fmaf(du, du, dvm[j]));
                 }
             }
             if (__builtin_amdgcn_ballot_w64(accc <= 0.0f) == 0) continue;
         }
         for (int g = gc; g < gc + kGroupCircle; g += kGroupTris) {
-            if (base + g >= p.n_tri) break;
+            if (base + g >= tri_stop) break;
             if (BLOCK_REJECT) {
                 // mrt_accel_* only (method MRT_ACCEL_BLOCK_REJECT): each edge function is monotone in x and
                 // in y, so its maximum over this lane's 4x4 block is its value at one
@@ -447,12 +467,12 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                 const float c1 = __builtin_fmaf(a1, xf, q1.y);
                 const float c2 = __builtin_fmaf(a2, xf, cc2);
 #pragma unroll
-                for (int j = 0; j < kLanePx; ++j) {
+                for (int j = 0; j < kTrLaneY; ++j) {
                     float v0 = __builtin_fmaf(b0, yf[j], c0);
                     float v1 = __builtin_fmaf(b1, yf[j], c1);
                     float v2 = __builtin_fmaf(b2, yf[j], c2);
 #pragma unroll
-                    for (int i = 0; i < kLanePx; ++i) {
+                    for (int i = 0; i < kTrLaneX; ++i) {
                         float m = __builtin_fminf(__builtin_fminf(v0, v1), v2);
                         acc = __builtin_fmaxf(acc, m);
                         v0 += a0; v1 += a1; v2 += a2;
@@ -473,23 +493,23 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                 const float c0 = __builtin_fmaf(a0, xf, q0.z);
                 const float c1 = __builtin_fmaf(a1, xf, q1.y);
                 const float c2 = __builtin_fmaf(a2, xf, cc2);
-                uint32_t mask = 0;
+                Mask mask = 0;
 #pragma unroll
-                for (int j = 0; j < kLanePx; ++j) {
+                for (int j = 0; j < kTrLaneY; ++j) {
                     float v0 = __builtin_fmaf(b0, yf[j], c0);
                     float v1 = __builtin_fmaf(b1, yf[j], c1);
                     float v2 = __builtin_fmaf(b2, yf[j], c2);
 #pragma unroll
-                    for (int i = 0; i < kLanePx; ++i) {
+                    for (int i = 0; i < kTrLaneX; ++i) {
                         float m = __builtin_fminf(__builtin_fminf(v0, v1), v2);
-                        if (m >= 0.0f) mask |= 1u << (j * kLanePx + i);
+                        if (m >= 0.0f) mask |= (Mask)1 << (j * kTrLaneX + i);
                         v0 += a0; v1 += a1; v2 += a2;
                     }
                 }
-                if (no_prefilter) mask = 0xFFFFu;
+                if (no_prefilter) mask = kAllPixels;
                 if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
-                const uint32_t total = list_pixels(mask, bx, by, lane, list, list_count);
-                exact_list<PROJ, true>(p, ti, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact, recorded);
+                const uint32_t total = list_pixels<kTrLaneX, kTrTileX, Mask>(mask, bx, by, lane, list, list_count);
+                exact_list<PROJ, true, kTrTileX>(p, ti, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact, recorded);
             }
         }
         }
@@ -498,32 +518,35 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     if (wave_active && !single_slice) {
         // tell shade_keys_kernel that this tile has keys worth reading (any wave of any slice may)
         if (p.tile_flags != nullptr && recorded && lane == 0)
-            p.tile_flags[(wave_lr0 / kWaveTile) * p.tiles_x + wave_x0 / kWaveTile] = 1u;
+            p.tile_flags[(wave_lr0 / kTrTileY) * p.tiles_x + wave_x0 / kTrTileX] = 1u;
         if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
     } else if (wave_active) {
         // The atomics went to the device's L2; make sure the loads below see them.
         __threadfence();
 #pragma unroll
-        for (int j = 0; j < kLanePx; ++j) {
-            const size_t off = (size_t)(lr0 + j) * pitch + x0;
-            const ulonglong2* row = reinterpret_cast<const ulonglong2*>(key_plane + off);
-            const ulonglong2 k01 = row[0], k23 = row[1];
-            int4 iv;
-            float4 tv;
-            iv.x = (int32_t)(uint32_t)k01.x; iv.y = (int32_t)(uint32_t)k01.y;
-            iv.z = (int32_t)(uint32_t)k23.x; iv.w = (int32_t)(uint32_t)k23.y;
-            // intersect.t_ of a miss is -1 (kernel.cl:363).
-            tv.x = iv.x < 0 ? -1.0f : __uint_as_float((uint32_t)(k01.x >> 32));
-            tv.y = iv.y < 0 ? -1.0f : __uint_as_float((uint32_t)(k01.y >> 32));
-            tv.z = iv.z < 0 ? -1.0f : __uint_as_float((uint32_t)(k23.x >> 32));
-            tv.w = iv.w < 0 ? -1.0f : __uint_as_float((uint32_t)(k23.y >> 32));
-            if (t_out != nullptr) {         // the (t, id) planes are written only for callers that ask
-                *reinterpret_cast<float4*>(t_out + off) = tv;
-                *reinterpret_cast<int4*>(id_out + off) = iv;
+        for (int j = 0; j < kTrLaneY; ++j) {
+#pragma unroll
+            for (int seg = 0; seg < kTrLaneX / 4; ++seg) {
+                const size_t off = (size_t)(lr0 + j) * pitch + x0 + 4 * seg;
+                const ulonglong2* row = reinterpret_cast<const ulonglong2*>(key_plane + off);
+                const ulonglong2 k01 = row[0], k23 = row[1];
+                int4 iv;
+                float4 tv;
+                iv.x = (int32_t)(uint32_t)k01.x; iv.y = (int32_t)(uint32_t)k01.y;
+                iv.z = (int32_t)(uint32_t)k23.x; iv.w = (int32_t)(uint32_t)k23.y;
+                // intersect.t_ of a miss is -1 (kernel.cl:363).
+                tv.x = iv.x < 0 ? -1.0f : __uint_as_float((uint32_t)(k01.x >> 32));
+                tv.y = iv.y < 0 ? -1.0f : __uint_as_float((uint32_t)(k01.y >> 32));
+                tv.z = iv.z < 0 ? -1.0f : __uint_as_float((uint32_t)(k23.x >> 32));
+                tv.w = iv.w < 0 ? -1.0f : __uint_as_float((uint32_t)(k23.y >> 32));
+                if (t_out != nullptr) {         // the (t, id) planes are written only for callers that ask
+                    *reinterpret_cast<float4*>(t_out + off) = tv;
+                    *reinterpret_cast<int4*>(id_out + off) = iv;
+                }
+                // Shade this row segment here rather than in a second launch: four pixels, one
+                // aligned 16-byte RGBA8 store per lane, 128 contiguous bytes per lane row of the wave.
+                if (p.fuse_shade) shade_row4<PROJ>(p, x0 + 4 * seg, lr0 + j, tv, iv);
             }
-            // Shade this row segment here rather than in a second launch: four pixels, one
-            // aligned 16-byte RGBA8 store per lane, 128 contiguous bytes per lane row of the wave.
-            if (p.fuse_shade) shade_row4<PROJ>(p, x0, lr0 + j, tv, iv);
         }
         if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
     }
@@ -1392,7 +1415,7 @@ __global__ __launch_bounds__(256) void shade_keys_kernel(const RenderParams p,
     unsigned long long key = ~0ull;
     if (p.tile_flags == nullptr) {
         key = key_plane[src];
-    } else if (p.tile_flags[(lr / kWaveTile) * p.tiles_x + x / kWaveTile] != 0u) {
+    } else if (p.tile_flags[(lr >> p.tile_y_log2) * p.tiles_x + (x >> p.tile_x_log2)] != 0u) {
         key = key_plane[src];
         if (key != ~0ull) key_plane[src] = ~0ull;
     }
@@ -1421,10 +1444,12 @@ __global__ __launch_bounds__(256) void shade_kernel(const RenderParams p,
     p.out[(size_t)lr * p.xres + x] = shade_pixel<PROJ>(p, x, image_row(p, lr), t_in[src], id_in[src]);
 }
 
-template __global__ void trace_kernel<MRT_PROJ_ORTHO, false>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_PERSP, false>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_ORTHO, true>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_PERSP, true>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, false, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, 8, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, false, 8, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, true, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, true, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void full_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, float*, int32_t*, uint32_t);
 template __global__ void full_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, float*, int32_t*, uint32_t);
 template __global__ void prep_full_records<MRT_PROJ_ORTHO>(const RenderParams, float4*, uint32_t*, uint32_t*);

@@ -20,6 +20,22 @@ constexpr int kBlockThreads = 64 * kBlockWavesX * kBlockWavesY;   // 256
 constexpr int kBlockTileX = kWaveTile * kBlockWavesX;             // 64
 constexpr int kBlockTileY = kWaveTile * kBlockWavesY;             // 64
 
+// trace_kernel's lane block is a template parameter: a lane owns LX x LY pixels, a wave 8 x 8
+// lanes (its tile), a block 2 x 2 waves.  4 x 4 is the shape of every other kernel; 8 x 4 spends
+// 10 % fewer instructions per (pixel, primitive) pair (the per-lane set-up of a record is shared
+// by 32 pixels instead of 16) and is what large frames use; small frames keep 4 x 4, whose
+// four times smaller tiles fill the GPU.  Block tiles are multiples of 64 pixels per axis, so
+// planes padded for either shape fit the other kernels.
+template <int LX, int LY>
+struct TraceShape {
+    static_assert(LX % 4 == 0 && LX <= 8 && LY % 4 == 0 && LY <= 8, "lane rows are stored 16 bytes at a time; block tiles are multiples of 64");
+    static constexpr int lane_x = LX, lane_y = LY;
+    static constexpr int tile_x = 8 * LX, tile_y = 8 * LY;
+    static constexpr int block_x = tile_x * kBlockWavesX, block_y = tile_y * kBlockWavesY;
+};
+using TraceNarrow = TraceShape<4, 4>;      // 32 x 32 tiles, 64 x 64 blocks
+using TraceWide = TraceShape<8, 4>;        // 64 x 32 tiles, 128 x 64 blocks
+
 // Prefilter records are staged through LDS in chunks of kChunkFloat4 float4
 // (12 KiB): 256 triangle records of three float4, or 768 sphere records of
 // one.  kGroup* primitives are tested between two "does any lane pass?" votes.
@@ -85,7 +101,8 @@ struct RenderParams {
     // wave that recorded a hit there, so that shade_keys_kernel reads (and puts back to "no hit")
     // only the keys of tiles something hit.  nullptr: every key is read and none is put back.
     uint32_t* tile_flags;
-    uint32_t tiles_x;               // tiles per row of the padded plane
+    uint32_t tiles_x;               // trace_kernel wave tiles per row of the padded plane
+    uint32_t tile_x_log2, tile_y_log2;  // ... and their size (32 x 32 or 64 x 32)
 };
 
 // What the record-building kernels (mrt_records.hip) need to know about a view, in double:

@@ -47,6 +47,35 @@ def test_native_scenes_match_golden(gpu_ctx, mrt, name):
         assert stats["exact"] == stats["pixels"]
 
 
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_native_scenes_wide_lane_blocks_match_golden(mrt, name):
+    """The 8x4-pixels-per-lane shape of the default kernel (what frames of 4 Mpixel and more get),
+    forced onto the 400x400 scenes: 64x32 wave tiles, 128x64 block tiles, 64-bit pixel masks."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    ctx = mrt.Context(device=0, flags=mrt.FLAG_TRACE_WIDE)
+    try:
+        r = gpu_render(ctx, mrt.LoadedScene(path=SCENES / f"{name}.json"))
+    finally:
+        ctx.close()
+    assert r["stats"].kernel == mrt.KERNEL_TRACE_WIDE
+    assert_same_hits(r, g)
+    check(r["rgba"], g["rgba"], g["ids"])
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 5), (129, 65), (257, 33), (640, 360)])
+def test_ragged_resolutions_wide_lane_blocks(mrt, oracle, w, h):
+    sc = scene_py.load_scene(SCENES / "teatime.json", xres=w, yres=h)
+    o = oracle.render(sc, threads=8)
+    ctx = mrt.Context(device=0, flags=mrt.FLAG_TRACE_WIDE)
+    try:
+        r = gpu_render(ctx, sc)
+    finally:
+        ctx.close()
+    assert r["stats"].kernel == mrt.KERNEL_TRACE_WIDE
+    assert_same_hits(r, o)
+    check(r["rgba"], o["rgba"], o["ids"], frac=0.0 if w * h < 2000 else 0.999)
+
+
 @pytest.mark.parametrize("name", ["scene_2spheres_persp_phong", "scene_gtri_persp_phong", "teatime"])
 def test_native_scenes_match_oracle_run_here(gpu_ctx, mrt, oracle, name):
     sc = scene_py.load_scene(SCENES / f"{name}.json")
@@ -445,13 +474,15 @@ def test_teatime_4k_full_frame_against_oracle(gpu_ctx, mrt, oracle):
     (3.3e10 ray-primitive tests on the host cores, about 10-20 s on 16 threads)."""
     ls = mrt.LoadedScene(text=mkscene.teatime(3840, 2160)).copy()
     r = gpu_render(gpu_ctx, ls)
+    assert r["stats"].kernel == mrt.KERNEL_TRACE_WIDE                      # 8.3 Mpixel: 8x4 pixels per lane
     o = oracle.render(ls, threads=16)
     assert (o["ids"] >= 0).sum() > 300000
     assert_same_hits(r, o)
     stats = check(r["rgba"], o["rgba"], o["ids"])
     assert stats["within_1lsb"] == stats["pixels"]
-    # the other kernels on the same frame: a 3x3 solve for every pair, and the accelerated entry points
-    for flags in (mrt.FLAG_FULL_TEST, "cull", "block", "grid"):
+    # the other kernels on the same frame: the 4x4 shape of the default kernel, a 3x3 solve for
+    # every pair, and the accelerated entry points
+    for flags in (mrt.FLAG_TRACE_NARROW, mrt.FLAG_FULL_TEST, "cull", "block", "grid"):
         ctx = mrt.renderer(device=0, kind=flags)
         try:
             r2 = gpu_render(ctx, ls)

@@ -89,6 +89,7 @@ def _scene(mrt, rng, kind, proj):
                                   "grazing_hires", "micro", "denormal", "giant"])
 def test_prefilters_never_drop_an_exact_hit(mrt, kind):
     fast = mrt.Context(device=0)
+    wide = mrt.Context(device=0, flags=mrt.FLAG_TRACE_WIDE)
     blk = mrt.Accel(device=0, method="block")
     cull = mrt.Accel(device=0, method="cull")
     grid = mrt.Accel(device=0, method="grid")
@@ -102,7 +103,7 @@ def test_prefilters_never_drop_an_exact_hit(mrt, kind):
             sc = _scene(mrt, rng, kind, proj)
             exact.set_scene(sc)
             _, ids_e, t_e, _ = exact.render(want_ids=True)
-            for ctx, kernel in ((fast, mrt.KERNEL_TRACE), (blk, mrt.KERNEL_TRACE_BLOCK), (cull, mrt.KERNEL_CULL),
+            for ctx, kernel in ((fast, mrt.KERNEL_TRACE), (wide, mrt.KERNEL_TRACE_WIDE), (blk, mrt.KERNEL_TRACE_BLOCK), (cull, mrt.KERNEL_CULL),
                                 (grid, mrt.KERNEL_GRID), (full, mrt.KERNEL_FULL)):
                 ctx.set_scene(sc)
                 _, ids_f, t_f, st_f = ctx.render(want_ids=True)
@@ -114,6 +115,7 @@ def test_prefilters_never_drop_an_exact_hit(mrt, kind):
         assert hits > 0, kind
     finally:
         fast.close()
+        wide.close()
         blk.close()
         cull.close()
         grid.close()

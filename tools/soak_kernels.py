@@ -17,7 +17,7 @@ mrt = mrt_pkg.load()
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 kinds = ["generic", "needle", "edge_on", "subpixel", "huge", "behind", "far", "tiny", "micro", "denormal", "giant"]
-kinds_of_renderer = {"default": 0, "full": mrt.FLAG_FULL_TEST, "cull": "cull", "block": "block", "grid": "grid"}
+kinds_of_renderer = {"default": 0, "wide": mrt.FLAG_TRACE_WIDE, "full": mrt.FLAG_FULL_TEST, "cull": "cull", "block": "block", "grid": "grid"}
 ctxs = {k: mrt.renderer(device=0, kind=v) for k, v in kinds_of_renderer.items()}
 exact = mrt.Context(device=0, flags=mrt.FLAG_NO_PREFILTER)
 bad = 0
