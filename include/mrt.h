@@ -400,6 +400,12 @@ int mrt_write_png_rgb(const char *path, const uint8_t *rgba, uint32_t xres, uint
  * CLHelpers.hpp.  Layouts mirror CLStructs.hpp:8-128 (packed; float3 = 16 B).
  * Inputs and outputs are HOST arrays owned by the caller; n may be any size
  * (the reference's fixed 160000 global size, CLHelpers.hpp:9, is not kept).
+ * Every call blocks until its results are in the caller's arrays, like the
+ * reference's helpers.  The device staging buffers belong to the ctx: they
+ * grow to the largest call seen and are freed by mrt_destroy, so repeated
+ * calls of one size allocate nothing (the reference creates and releases its
+ * cl::Buffers in every call, CLHelpers.hpp:93-104); copies and kernels run on
+ * the ctx's own stream, not on the null stream.
  * ---------------------------------------------------------------------- */
 #pragma pack(push, 1)
 typedef struct mrt_cl_float3 { float s[4]; } mrt_cl_float3;              /* cl_float3  16 B */

@@ -129,6 +129,9 @@ struct mrt_ctx {
     // another stream can be ordered after it (the working planes above are shared by all frames).
     uint32_t last_kernel = MRT_KERNEL_TRACE, last_slices = 1;
     uint32_t last_pitch = 0;                 // pitch of the (t, id) planes the last frame wrote
+    // mrt_stage_*: device staging buffers that grow on demand and live as long as the ctx
+    void* stage_buf[3] = {nullptr, nullptr, nullptr};
+    size_t stage_cap[3] = {0, 0, 0};
     hipEvent_t frame_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool frame_pending = false;
@@ -487,6 +490,27 @@ int fill_stats(mrt_ctx* ctx, mrt_stats* st, uint32_t rows) {
 // Shared with mrt_stages.hip (not part of the public ABI).
 extern "C" int mrt_stage_set_error_(mrt_ctx* ctx, int code, const char* msg) { return fail(ctx, code, msg ? msg : ""); }
 extern "C" int mrt_stage_device_(const mrt_ctx* ctx) { return ctx ? ctx->device : 0; }
+// Staging buffer `slot` of the ctx with room for `bytes` (the ctx's GPU must be current); the
+// previous contents are not kept when it grows.  nullptr + the ctx's error on failure.
+extern "C" void* mrt_stage_buffer_(mrt_ctx* ctx, int slot, size_t bytes) {
+    if (!ctx || slot < 0 || slot >= 3) return nullptr;
+    if (bytes == 0) bytes = 1;
+    if (bytes > ctx->stage_cap[slot]) {
+        // an earlier stage call may still be reading the old buffer on the ctx's stream
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->stage_buf[slot]) (void)hipFree(ctx->stage_buf[slot]);
+        ctx->stage_buf[slot] = nullptr;
+        ctx->stage_cap[slot] = 0;
+        const hipError_t e = hipMalloc(&ctx->stage_buf[slot], bytes);
+        if (e != hipSuccess) {
+            ctx->stage_buf[slot] = nullptr;
+            fail(ctx, MRT_ERR_HIP, std::string("hipMalloc of a stage buffer: ") + hipGetErrorString(e));
+            return nullptr;
+        }
+        ctx->stage_cap[slot] = bytes;
+    }
+    return ctx->stage_buf[slot];
+}
 // Shared with mrt_accel.hip (mrt_internal.hpp).
 extern "C" const mrt::RenderParams* mrt_ctx_params_(const mrt_ctx* ctx) { return &ctx->params; }
 extern "C" void* mrt_ctx_stream_(const mrt_ctx* ctx) { return (void*)ctx->stream; }
@@ -557,6 +581,7 @@ void mrt_destroy(mrt_ctx* ctx) {
     if (ctx->d_tile_flags) (void)hipFree(ctx->d_tile_flags);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
+    for (int k = 0; k < 3; ++k) if (ctx->stage_buf[k]) (void)hipFree(ctx->stage_buf[k]);
     for (int k = 0; k < 3; ++k) if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->frame_done) (void)hipEventDestroy(ctx->frame_done);
     if (ctx->records_ready) (void)hipEventDestroy(ctx->records_ready);

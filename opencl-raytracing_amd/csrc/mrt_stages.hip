@@ -21,6 +21,8 @@
 
 extern "C" int mrt_stage_set_error_(mrt_ctx* ctx, int code, const char* msg);
 extern "C" int mrt_stage_device_(const mrt_ctx* ctx);
+extern "C" void* mrt_stage_buffer_(mrt_ctx* ctx, int slot, size_t bytes);
+extern "C" void* mrt_ctx_stream_(const mrt_ctx* ctx);
 
 namespace mrt {
 
@@ -142,11 +144,23 @@ __global__ void stage_shade_kernel(const uint32_t* __restrict__ xs, int n, Phong
 
 namespace {
 
+// A staging buffer of the ctx (slot 0..2): the ctx owns it, it grows on demand and is reused by
+// every later stage call, so a steady stream of calls allocates nothing.
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    bool take(mrt_ctx* ctx, int slot, size_t bytes) { p = mrt_stage_buffer_(ctx, slot, bytes); return p != nullptr; }
 };
+#define STAGE_BUF(buf, slot, bytes)                                  \
+    do {                                                             \
+        if (!(buf).take(ctx, (slot), (bytes))) return MRT_ERR_HIP;    \
+    } while (0)
+// Copies and kernels of a stage call go to the ctx's own stream; the call returns when the
+// results are in the caller's arrays (the reference's helpers block too: CLHelpers.hpp:106-109).
+#define STAGE_COPY(dst, src, bytes, kind)                                                    \
+    do {                                                                                     \
+        STAGE_TRY(hipMemcpyAsync((dst), (src), (bytes), (kind), stage_stream));               \
+        if ((kind) == hipMemcpyDeviceToHost) STAGE_TRY(hipStreamSynchronize(stage_stream));   \
+    } while (0)
 
 #define STAGE_TRY(expr)                                                                        \
     do {                                                                                       \
@@ -190,21 +204,22 @@ int rays_common(mrt_ctx* ctx, const mrt_cl_cam* camera, const mrt_cl_float2* uv,
     if (rc != MRT_OK) return rc;
     if (!camera) return mrt_stage_set_error_(ctx, MRT_ERR_INVALID, "camera is NULL");
     if (n == 0) return MRT_OK;
+    hipStream_t stage_stream = (hipStream_t)mrt_ctx_stream_(ctx);
     DevBuf d_uv, d_rays;
-    STAGE_TRY(d_uv.alloc((size_t)n * 8));
-    STAGE_TRY(d_rays.alloc((size_t)n * 32));
-    STAGE_TRY(hipMemcpy(d_uv.p, uv, (size_t)n * 8, hipMemcpyHostToDevice));
+    STAGE_BUF(d_uv, 0, (size_t)n * 8);
+    STAGE_BUF(d_rays, 1, (size_t)n * 32);
+    STAGE_COPY(d_uv.p, uv, (size_t)n * 8, hipMemcpyHostToDevice);
     // Keep the caller's padding floats (the kernels never write .s[3]).
-    STAGE_TRY(hipMemcpy(d_rays.p, rays_out, (size_t)n * 32, hipMemcpyHostToDevice));
+    STAGE_COPY(d_rays.p, rays_out, (size_t)n * 32, hipMemcpyHostToDevice);
     std::vector<mrt_cl_ray> tmp((size_t)n);
     if (persp)
-        hipLaunchKernelGGL(mrt::stage_rays_kernel<MRT_PROJ_PERSP>, grid_for(n), dim3(256), 0, 0, cam_of(camera),
+        hipLaunchKernelGGL(mrt::stage_rays_kernel<MRT_PROJ_PERSP>, grid_for(n), dim3(256), 0, stage_stream, cam_of(camera),
                            (const float2*)d_uv.p, n, focal, (float4*)d_rays.p);
     else
-        hipLaunchKernelGGL(mrt::stage_rays_kernel<MRT_PROJ_ORTHO>, grid_for(n), dim3(256), 0, 0, cam_of(camera),
+        hipLaunchKernelGGL(mrt::stage_rays_kernel<MRT_PROJ_ORTHO>, grid_for(n), dim3(256), 0, stage_stream, cam_of(camera),
                            (const float2*)d_uv.p, n, focal, (float4*)d_rays.p);
     STAGE_TRY(hipGetLastError());
-    STAGE_TRY(hipMemcpy(tmp.data(), d_rays.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+    STAGE_COPY(tmp.data(), d_rays.p, (size_t)n * 32, hipMemcpyDeviceToHost);
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k) {
             rays_out[i].origin.s[k] = tmp[(size_t)i].origin.s[k];
@@ -237,17 +252,18 @@ int shade_common(mrt_ctx* ctx, const mrt_cl_intersect* xsects, int n, mrt_cl_rgb
             hl.push_back(make_float4(lights[l].color.s[0], lights[l].color.s[1], lights[l].color.s[2], 0.f));
         }
     }
+    hipStream_t stage_stream = (hipStream_t)mrt_ctx_stream_(ctx);
     DevBuf d_x, d_l, d_o;
-    STAGE_TRY(d_x.alloc((size_t)n * 80));
-    STAGE_TRY(d_l.alloc(hl.size() * sizeof(float4)));
-    STAGE_TRY(d_o.alloc((size_t)n * 16));
-    STAGE_TRY(hipMemcpy(d_x.p, xsects, (size_t)n * 80, hipMemcpyHostToDevice));
-    if (!hl.empty()) STAGE_TRY(hipMemcpy(d_l.p, hl.data(), hl.size() * sizeof(float4), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(mrt::stage_shade_kernel, grid_for(n), dim3(256), 0, 0, (const uint32_t*)d_x.p, n, k,
+    STAGE_BUF(d_x, 0, (size_t)n * 80);
+    STAGE_BUF(d_l, 1, hl.size() * sizeof(float4));
+    STAGE_BUF(d_o, 2, (size_t)n * 16);
+    STAGE_COPY(d_x.p, xsects, (size_t)n * 80, hipMemcpyHostToDevice);
+    if (!hl.empty()) STAGE_COPY(d_l.p, hl.data(), hl.size() * sizeof(float4), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(mrt::stage_shade_kernel, grid_for(n), dim3(256), 0, stage_stream, (const uint32_t*)d_x.p, n, k,
                        (const float4*)d_l.p, (float4*)d_o.p);
     STAGE_TRY(hipGetLastError());
     std::vector<float4> res((size_t)n);
-    STAGE_TRY(hipMemcpy(res.data(), d_o.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+    STAGE_COPY(res.data(), d_o.p, (size_t)n * 16, hipMemcpyDeviceToHost);
     for (int i = 0; i < n; ++i) {
         out[i].r = res[(size_t)i].x; out[i].g = res[(size_t)i].y; out[i].b = res[(size_t)i].z;
         // flat_shader never writes .a (kernel.cl:381-396); phong_shader copies
@@ -269,15 +285,16 @@ int mrt_stage_uv(mrt_ctx* ctx, const mrt_cl_float3* positions, const mrt_cl_vp* 
     if (rc != MRT_OK) return rc;
     if (!viewport) return mrt_stage_set_error_(ctx, MRT_ERR_INVALID, "viewport is NULL");
     if (n == 0) return MRT_OK;
+    hipStream_t stage_stream = (hipStream_t)mrt_ctx_stream_(ctx);
     DevBuf d_pos, d_uv;
-    STAGE_TRY(d_pos.alloc((size_t)n * 16));
-    STAGE_TRY(d_uv.alloc((size_t)n * 8));
-    STAGE_TRY(hipMemcpy(d_pos.p, positions, (size_t)n * 16, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(mrt::stage_uv_kernel, grid_for(n), dim3(256), 0, 0, (const float4*)d_pos.p, viewport->left,
+    STAGE_BUF(d_pos, 0, (size_t)n * 16);
+    STAGE_BUF(d_uv, 1, (size_t)n * 8);
+    STAGE_COPY(d_pos.p, positions, (size_t)n * 16, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(mrt::stage_uv_kernel, grid_for(n), dim3(256), 0, stage_stream, (const float4*)d_pos.p, viewport->left,
                        viewport->right, viewport->top, viewport->bottom, viewport->x_resolution,
                        viewport->y_resolution, n, (float2*)d_uv.p);
     STAGE_TRY(hipGetLastError());
-    STAGE_TRY(hipMemcpy(uv_out, d_uv.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    STAGE_COPY(uv_out, d_uv.p, (size_t)n * 8, hipMemcpyDeviceToHost);
     return MRT_OK;
 }
 
@@ -314,18 +331,19 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
             geo[3 * (size_t)j + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    hipStream_t stage_stream = (hipStream_t)mrt_ctx_stream_(ctx);
     DevBuf d_geo, d_rays, d_out;
-    STAGE_TRY(d_geo.alloc(geo.size() * sizeof(float4)));
-    STAGE_TRY(d_rays.alloc((size_t)n_rays * 32));
-    STAGE_TRY(d_out.alloc((size_t)n_rays * sizeof(mrt::HitOut)));
-    if (!geo.empty()) STAGE_TRY(hipMemcpy(d_geo.p, geo.data(), geo.size() * sizeof(float4), hipMemcpyHostToDevice));
-    STAGE_TRY(hipMemcpy(d_rays.p, rays, (size_t)n_rays * 32, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(mrt::stage_intersect_kernel, grid_for(n_rays), dim3(256), 0, 0, (const float4*)d_geo.p,
+    STAGE_BUF(d_geo, 0, geo.size() * sizeof(float4));
+    STAGE_BUF(d_rays, 1, (size_t)n_rays * 32);
+    STAGE_BUF(d_out, 2, (size_t)n_rays * sizeof(mrt::HitOut));
+    if (!geo.empty()) STAGE_COPY(d_geo.p, geo.data(), geo.size() * sizeof(float4), hipMemcpyHostToDevice);
+    STAGE_COPY(d_rays.p, rays, (size_t)n_rays * 32, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(mrt::stage_intersect_kernel, grid_for(n_rays), dim3(256), 0, stage_stream, (const float4*)d_geo.p,
                        n_objects, (const float4*)d_rays.p, n_rays, t_upper_bound, t_lower_bound,
                        (mrt::HitOut*)d_out.p);
     STAGE_TRY(hipGetLastError());
     std::vector<mrt::HitOut> res((size_t)n_rays);
-    STAGE_TRY(hipMemcpy(res.data(), d_out.p, (size_t)n_rays * sizeof(mrt::HitOut), hipMemcpyDeviceToHost));
+    STAGE_COPY(res.data(), d_out.p, (size_t)n_rays * sizeof(mrt::HitOut), hipMemcpyDeviceToHost);
     for (int i = 0; i < n_rays; ++i) {
         const mrt::HitOut& h = res[(size_t)i];
         int id;

@@ -604,10 +604,11 @@ def test_render_is_deterministic(gpu_ctx, mrt):
         gpu_ctx.render(out=np.empty((10, 10, 4), np.uint8))
 
 
+@pytest.mark.parametrize("shape", ["narrow", "wide"])
 @pytest.mark.parametrize("world,band", [(2, 64), (3, 16), (8, 64), (4, 7)])
-def test_band_partition_invariance(gpu_ctx, mrt, world, band):
+def test_band_partition_invariance(gpu_ctx, mrt, world, band, shape):
     """Interleaved row bands rendered rank by rank into device memory and put
-    back together equal the single full-frame render."""
+    back together equal the single full-frame render, with both lane shapes of the default kernel."""
     import torch
     ls = mrt.LoadedScene(text=mkscene.teatime(640, 360)).copy()
     gpu_ctx.set_scene(ls)
@@ -616,10 +617,16 @@ def test_band_partition_invariance(gpu_ctx, mrt, world, band):
     rows = [mrt.band_rows(yres, band, r, world) for r in range(world)]
     stride = max(rows) * xres * 4
     gathered = torch.zeros((world, stride), dtype=torch.uint8, device="cuda:0")
-    for r in range(world):
-        gpu_ctx.render_bands_device(band, r, world, gathered[r].data_ptr(), stride,
-                                    stream=torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+    ctx = mrt.Context(device=0, flags=mrt.FLAG_TRACE_WIDE if shape == "wide" else mrt.FLAG_TRACE_NARROW)
+    try:
+        ctx.set_scene(ls)
+        for r in range(world):
+            st = ctx.render_bands_device(band, r, world, gathered[r].data_ptr(), stride,
+                                         stream=torch.cuda.current_stream().cuda_stream, timed=True)
+            assert st.kernel == (mrt.KERNEL_TRACE_WIDE if shape == "wide" else mrt.KERNEL_TRACE)
+        torch.cuda.synchronize()
+    finally:
+        ctx.close()
     img = mrt.bands_to_image(gathered.cpu().numpy(), stride, xres, yres, band, world)
     assert np.array_equal(img, full)
 
