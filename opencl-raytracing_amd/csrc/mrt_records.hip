@@ -63,7 +63,8 @@ __device__ Edge make_edge(double a, double b, double c, double margin, double xr
         A = 0; B = 0; C = 1.0;
     }
     // Rounding of the three coefficients to float and of the two fused
-    // multiply-adds (plus up to three additions along a row) in the kernel.
+    // multiply-adds (plus up to seven additions along a lane's row) in the kernel:
+    // (3 + 2 + 7) half-ulps of the largest magnitude in play, 6 of the 16 budgeted.
     C += 16.0 * (1.0 / 16777216.0) * (fabs(A) * xres + fabs(B) * yres + fabs(C));
     if (!(fabs(C) < 1e30)) C = (C > 0 || C != C) ? 1e30 : -1e30;
     Edge e;

@@ -31,6 +31,14 @@ def gpu_render(ctx, scene):
     return {"rgba": img, "ids": ids, "t": t, "stats": st}
 
 
+def gpu_render_flags(mrt, scene, flags):
+    ctx = mrt.Context(device=0, flags=flags)
+    try:
+        return gpu_render(ctx, scene)
+    finally:
+        ctx.close()
+
+
 def assert_same_hits(g, o):
     assert np.array_equal(g["ids"], o["ids"]), int((g["ids"] != o["ids"]).sum())
     assert np.array_equal(g["t"], o["t"])
@@ -108,11 +116,14 @@ def test_random_soup_matches_oracle(gpu_ctx, mrt, oracle, proj, seed):
     check(r["rgba"], o["rgba"], o["ids"])
 
 
-def test_prefilter_is_a_superset_of_exact(mrt, oracle):
+@pytest.mark.parametrize("shape", ["narrow", "wide"])
+def test_prefilter_is_a_superset_of_exact(mrt, oracle, shape):
     """The conservative edge-function prefilter may only drop pairs the exact
-    test rejects: with and without it the winners and t must be identical."""
-    a = mrt.Context(device=0, flags=mrt.FLAG_COUNT_EXACT)
-    b = mrt.Context(device=0, flags=mrt.FLAG_NO_PREFILTER | mrt.FLAG_COUNT_EXACT)
+    test rejects: with and without it the winners and t must be identical, in both lane shapes
+    of the kernel (and both shapes count the same survivors: the tests are per pixel)."""
+    shape_flag = mrt.FLAG_TRACE_WIDE if shape == "wide" else mrt.FLAG_TRACE_NARROW
+    a = mrt.Context(device=0, flags=mrt.FLAG_COUNT_EXACT | shape_flag)
+    b = mrt.Context(device=0, flags=mrt.FLAG_NO_PREFILTER | mrt.FLAG_COUNT_EXACT | shape_flag)
     try:
         cases = [scene_py.load_scene(SCENES / "teatime.json", xres=960, yres=540,
                                      viewport=(-16 / 9, 16 / 9, 1.0, -1.0)),
@@ -127,6 +138,18 @@ def test_prefilter_is_a_superset_of_exact(mrt, oracle):
             n_pairs = sc.struct.xres * sc.struct.yres * sc.n_objects
             assert rb["stats"].exact_tests >= sc.struct.xres * sc.struct.yres * sc.struct.n_tris
             assert ra["stats"].exact_tests < 0.05 * n_pairs   # the filter does reject almost everything
+            assert ra["stats"].kernel == rb["stats"].kernel == (mrt.KERNEL_TRACE_WIDE if shape == "wide" else mrt.KERNEL_TRACE)
+            if shape == "wide":       # the per-pixel funnel passes the same pairs whatever the lane block
+                # (up to the rounding of the incremental edge evaluation and the padding pixels of the last tiles)
+                narrow = mrt.Context(device=0, flags=mrt.FLAG_COUNT_EXACT | mrt.FLAG_TRACE_NARROW)
+                try:
+                    rn = gpu_render(narrow, sc)
+                finally:
+                    narrow.close()
+                assert abs(rn["stats"].exact_tests - ra["stats"].exact_tests) <= 64 + ra["stats"].exact_tests // 1000
+                rc = gpu_render_flags(mrt, sc, mrt.FLAG_NO_CIRCLE | mrt.FLAG_COUNT_EXACT | shape_flag)
+                assert_same_hits(ra, rc)
+                assert rc["stats"].exact_tests == ra["stats"].exact_tests
     finally:
         a.close()
         b.close()
