@@ -118,7 +118,7 @@ struct mrt_ctx {
     // Every key of d_key is "no hit" (all ones): sliced frames keep it so (shade_keys_kernel puts
     // back what the frame wrote), which saves the memset; false after anything else touched it.
     bool keys_clean = false;
-    uint32_t* d_tile_flags = nullptr;        // one word per 32x32 tile of the padded plane
+    uint32_t* d_tile_flags = nullptr;        // one word per trace_kernel wave tile of the padded plane (sized for 32x32 tiles)
     size_t tile_flag_elems = 0;
     uint32_t* d_out = nullptr;
     size_t out_elems = 0;

@@ -6,10 +6,10 @@
 
 namespace mrt {
 
-// Geometry of the pixel->lane mapping.  One 64-lane wavefront owns a 32x32
-// pixel tile: lanes form an 8x8 grid and each lane owns a 4x4 block, so every
-// record a wave fetches from LDS is reused for 16 pixels per lane and each
-// lane's row segment is one aligned 16-byte RGBA8 store.
+// Geometry of the pixel->lane mapping of every kernel but trace_kernel (which has two shapes,
+// TraceShape below).  One 64-lane wavefront owns a 32x32 pixel tile: lanes form an 8x8 grid and
+// each lane owns a 4x4 block, so every record a wave fetches from LDS is reused for 16 pixels
+// per lane and each lane's row segment is one aligned 16-byte RGBA8 store.
 constexpr int kLanePx = 4;                 // pixels per lane, per axis
 constexpr int kWaveTile = 8 * kLanePx;     // 32
 #ifndef MRT_BLOCK_WAVES_Y
@@ -97,7 +97,7 @@ struct RenderParams {
     int32_t* ids;                   // optional, local_rows x xres
     float* tvals;                   // optional
     unsigned long long* exact_counter;  // optional
-    // Sliced trace_kernel frames with ctx-owned planes: one word per 32x32 wave tile, set by any
+    // Sliced trace_kernel frames with ctx-owned planes: one word per wave tile, set by any
     // wave that recorded a hit there, so that shade_keys_kernel reads (and puts back to "no hit")
     // only the keys of tiles something hit.  nullptr: every key is read and none is put back.
     uint32_t* tile_flags;
