@@ -27,7 +27,9 @@ executed VALU issue rate as a fraction of the nominal 78.6 T lane-ops/s.  `cpu_b
 the CPU oracle (oracle/mrt_oracle.c, a restatement of the reference arithmetic -- the reference
 has no CPU path of its own and may not be run) on a bounded row sample of the same frame.
 `secondary` carries the other benchmark configurations; with N > 1 the strong-scaling frames
-(16384^2 soup, 8K teatime) are also reported as flat soup16k_* / teatime8k_* keys.
+(16384^2 soup, 8K teatime: one fixed frame over the N ranks) are also reported as flat soup16k_* /
+teatime8k_* keys, among them *_one_gpu_ms_per_frame (the same frame on rank 0's GPU alone, timed
+in the same run) and *_speedup_vs_one_gpu.
 """
 import argparse
 import json
@@ -214,14 +216,35 @@ def secondary_workloads(env, mkscene):
                                         job.local[0].numel(), stream=env.stream.cuda_stream, timed=True)
         return {"grid_build_ms_per_view": s.build_ms, "grid_cells": s.cells, "grid_refs": s.refs}
 
+    def one_gpu_reference(scene, name, steps):
+        """With N > 1: the same frame on rank 0's GPU alone, in this same run (no gather; the other
+        ranks wait on the host), so that the strong-scaling speedup has its own denominator."""
+        if env.world == 1:
+            return
+        if env.rank == 0:
+            solo = Env()
+            solo.__dict__.update(env.__dict__)
+            solo.world, solo.rank, solo.use_dist = 1, 0, False
+            job = Job(solo, scene)
+            elapsed = job.timed(steps, 1)
+            job.close()
+            res[name]["one_gpu_ms_per_frame"] = elapsed / steps * 1e3
+            res[name]["speedup_vs_one_gpu"] = res[name]["one_gpu_ms_per_frame"] / res[name]["ms_per_frame"]
+        host_side_handshake(env, f"one_gpu_{name}")
+        env.dist.barrier()
+
     # The 16384 x 16384 triangle soup, one frame split over all ranks (strong scaling).
-    job = Job(env, mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy())
+    soup16k = mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy()
+    job = Job(env, soup16k)
     frame_stats(job, "soup16k_16384x16384", steps=3, warmup=1, extra={"scaling": "strong"})
     job.close()
+    one_gpu_reference(soup16k, "soup16k_16384x16384", steps=3)
     # teatime at 7680 x 4320, split over all ranks.
-    job = Job(env, mrt.LoadedScene(text=mkscene.teatime(7680, 4320)).copy())
+    tea8k = mrt.LoadedScene(text=mkscene.teatime(7680, 4320)).copy()
+    job = Job(env, tea8k)
     frame_stats(job, "teatime_8k_7680x4320", steps=5, warmup=1, extra={"scaling": "strong"})
     job.close()
+    one_gpu_reference(tea8k, "teatime_8k_7680x4320", steps=5)
     if env.world == 1:
         # The shipped scenes at their native 400 x 400 (the only size the reference itself can render).
         for name in ("scene_2spheres_persp_phong", "scene_gtri_persp_phong", "teatime"):
@@ -481,6 +504,9 @@ def main():
                     out[f"{key}_ms_per_frame"] = sec[name]["ms_per_frame"]
                     out[f"{key}_mrays_per_s"] = sec[name]["mrays_per_s"]
                     out[f"{key}_scaling"] = "strong"
+                    if "speedup_vs_one_gpu" in sec[name]:
+                        out[f"{key}_one_gpu_ms_per_frame"] = sec[name]["one_gpu_ms_per_frame"]
+                        out[f"{key}_speedup_vs_one_gpu"] = sec[name]["speedup_vs_one_gpu"]
     if not args.no_secondary:
         if env.use_dist:
             torch.cuda.synchronize(env.dev)
