@@ -30,7 +30,8 @@ template <int PROJ>
 __global__ void cull_trace_kernel(const RenderParams p, float* t_out, int32_t* id_out, uint32_t pitch);
 template <int PROJ>
 __global__ void full_trace_kernel(const RenderParams p, const float4* full_rec, const uint32_t* full_ids,
-                                  const uint32_t* class_counts, float* t_out, int32_t* id_out, uint32_t pitch);
+                                  const uint32_t* class_counts, unsigned long long* key_plane, float* t_out,
+                                  int32_t* id_out, uint32_t pitch);
 template <int PROJ>
 __global__ void prep_full_records(const RenderParams p, float4* rec, uint32_t* ids, uint32_t* counts);
 __global__ void build_triangle_records(const ViewDerived w, const float4* tri_exact, uint32_t n_tri,
@@ -314,12 +315,27 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     if (cull && !planes.own)
         return fail(ctx, MRT_ERR_INVALID, "the tile-cull kernel needs per-pixel planes of its own; not available without allocation");
 
-    // Working planes.  trace_kernel keeps the closest hit of every pixel in a 64-bit key plane;
-    // the tile cull hands (t, id) planes to shade_kernel; full_trace_kernel needs neither.
+    // full_trace_kernel in layers (see the kernel): a frame of few waves -- a 4K frame is four
+    // rounds of them, which start and finish in step -- is cut into about 64 K waves, each layer
+    // a share of the record chunks; the layers meet in the key plane.  MRT_FORCE_SLICES overrides.
+    const dim3 fgrid2(pitch / mrt::kBlockTileX, prow / mrt::kFullBlockH);      // blocks of 64 x 32 pixels
+    uint32_t full_layers = 1;
+    if (full) {
+        const uint32_t waves = fgrid2.x * fgrid2.y * (mrt::kBlockThreads / 64);
+        const uint32_t chunks = p.n_tri_padded / mrt::kChunkTris;
+        const char* force = std::getenv("MRT_FORCE_SLICES");          // tuning aid
+        full_layers = force ? (uint32_t)std::atoi(force) : (65536u + waves - 1) / waves;
+        if (full_layers > chunks) full_layers = chunks;
+        if (full_layers < 1) full_layers = 1;
+        if (!planes.own && plane_elems > planes.key_capacity) full_layers = 1;    // no room for keys: one layer needs none
+    }
+
+    // Working planes.  trace_kernel (and full_trace_kernel in layers) keeps the closest hit of
+    // every pixel in a 64-bit key plane; the tile cull hands (t, id) planes to shade_kernel.
     unsigned long long* d_key = nullptr;
     float* d_t = nullptr;
     int32_t* d_id = nullptr;
-    if (!full && !cull) {
+    if ((!full && !cull) || full_layers > 1) {
         if (planes.own) {
             const int rc = ensure_keys(ctx, plane_elems);
             if (rc != MRT_OK) return rc;
@@ -348,7 +364,6 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
 
     const dim3 tgrid(pitch / block_x, prow / block_y);
     const dim3 cgrid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY);      // cull_trace_kernel: 64 x 64
-    const dim3 fgrid(pitch / mrt::kBlockTileX, prow / mrt::kFullBlockH);      // full_trace_kernel: blocks of 64 x 32 pixels
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], stream));
     // trace_kernel and full_trace_kernel shade their own pixels in the epilogue (one launch per
     // frame); 16-byte stores need rows and buffer aligned to four pixels.  The tile cull runs at
@@ -376,8 +391,11 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
             p.slice_tris = per * kMinSliceTris;
             p.prim_slices = (units + per - 1) / per;
         }
+    } else if (full) {
+        p.prim_slices = full_layers;
     }
     const dim3 zgrid(tgrid.x, tgrid.y, p.prim_slices);
+    const dim3 fgrid(fgrid2.x, fgrid2.y, p.prim_slices);
     p.tile_flags = nullptr;
     p.tiles_x = pitch / tile_x;
     p.tile_x_log2 = wide ? 6u : 5u;
@@ -402,11 +420,11 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     if (full && persp) {
         kernel = MRT_KERNEL_FULL;
         hipLaunchKernelGGL((mrt::full_trace_kernel<MRT_PROJ_PERSP>), fgrid, tb, 0, stream, p,
-                           (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, d_t, d_id, pitch);
+                           (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, d_key, d_t, d_id, pitch);
     } else if (full) {
         kernel = MRT_KERNEL_FULL;
         hipLaunchKernelGGL((mrt::full_trace_kernel<MRT_PROJ_ORTHO>), fgrid, tb, 0, stream, p,
-                           (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, d_t, d_id, pitch);
+                           (const float4*)ctx->d_full_rec, ctx->d_full_ids, ctx->d_full_counts, d_key, d_t, d_id, pitch);
     } else if (cull && persp) {
         kernel = MRT_KERNEL_CULL;
         hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_PERSP>), cgrid, tb, 0, stream, p, d_t, d_id, pitch);

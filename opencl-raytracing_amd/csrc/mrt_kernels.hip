@@ -1206,6 +1206,7 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                                                                   const float4* __restrict__ full_rec,
                                                                   const uint32_t* __restrict__ full_ids,
                                                                   const uint32_t* __restrict__ class_counts,
+                                                                  unsigned long long* __restrict__ key_plane,
                                                                   float* __restrict__ t_out,
                                                                   int32_t* __restrict__ id_out, uint32_t pitch) {
     __shared__ float4 s_rec[kFullChunkFloat4];
@@ -1250,8 +1251,15 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
 
     shared_part = mk3(in_vgpr(shared_part.x), in_vgpr(shared_part.y), in_vgpr(shared_part.z));
 
+    // A frame of few waves (a 4K frame is four rounds of them) is cut into p.prim_slices grid
+    // layers: layer z takes every prim_slices-th chunk of records, starting at chunk z, and the
+    // layers' closest hits meet in the key plane under atomicMin (see kNoHitKey), which
+    // shade_keys_kernel then decodes and shades.  One layer keeps everything in registers.
+    const uint32_t n_layers = p.prim_slices > 1 ? p.prim_slices : 1u;
+    const uint32_t layer = n_layers > 1 ? blockIdx.z : 0u;
+
     // ---- spheres: object ids 0 .. n_sph-1 ----
-    for (uint32_t base = 0; base < p.n_sph; base += kChunkFloat4) {
+    for (uint32_t base = layer * kChunkFloat4; base < p.n_sph; base += n_layers * kChunkFloat4) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kChunkFloat4 / kBlockThreads; ++k) {
@@ -1294,7 +1302,7 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
 
     // ---- triangles: object ids n_sph .. n_sph+n_tri-1, one sign group after the other ----
     auto sign_group = [&](uint32_t first, uint32_t n) {
-        for (uint32_t base = 0; base < n; base += kChunkTris) {
+        for (uint32_t base = layer * kChunkTris; base < n; base += n_layers * kChunkTris) {
             __syncthreads();
             // the buffer has a chunk of slack beyond the last record
 #pragma unroll
@@ -1374,7 +1382,22 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
     sign_group(0u, n_pos);
     sign_group(p.n_tri - n_neg, n_neg);
 
-    if (wave_active) {
+    if (wave_active && n_layers > 1) {
+        // this layer's closest hits into the key plane (padded to whole tiles: no bounds checks)
+        bool rec = false;
+#pragma unroll
+        for (int s = 0; s < kFullSlots; ++s) {
+            if (best_id[s] >= 0) {
+                atomicMin(&key_plane[(size_t)(lr0 + s / kFullPxX) * pitch + x0 + s % kFullPxX],
+                          ((unsigned long long)__float_as_uint(best_t[s]) << 32) | (uint32_t)best_id[s]);
+                rec = true;
+            }
+        }
+        if (p.tile_flags != nullptr && __builtin_amdgcn_ballot_w64(rec) != 0 && lane == 0)
+            p.tile_flags[(wave_lr0 >> p.tile_y_log2) * p.tiles_x + (wave_x0 >> p.tile_x_log2)] = 1u;
+        if (p.exact_counter != nullptr && layer == 0)
+            atomicAdd(p.exact_counter, (unsigned long long)kFullSlots * ((unsigned long long)p.n_sph + p.n_tri));
+    } else if (wave_active) {
 #pragma unroll
         for (int j = 0; j < kFullPxY; ++j) {
             const size_t off = (size_t)(lr0 + j) * pitch + x0;
@@ -1450,8 +1473,8 @@ template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, 8, 4>(const RenderP
 template __global__ void trace_kernel<MRT_PROJ_PERSP, false, 8, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_ORTHO, true, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_PERSP, true, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void full_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, float*, int32_t*, uint32_t);
-template __global__ void full_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, float*, int32_t*, uint32_t);
+template __global__ void full_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void full_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void prep_full_records<MRT_PROJ_ORTHO>(const RenderParams, float4*, uint32_t*, uint32_t*);
 template __global__ void prep_full_records<MRT_PROJ_PERSP>(const RenderParams, float4*, uint32_t*, uint32_t*);
 template __global__ void cull_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, float*, int32_t*, uint32_t);
