@@ -74,6 +74,14 @@ def test_noalloc_other_kernels_and_limits(mrt):
             assert np.array_equal(out, ref), flags
         finally:
             ctx.close()
+    # the full-test kernel merges its layers in the key plane when the frame is small; a frame
+    # beyond the fixed array runs as one layer, which needs no keys at all
+    ctx = mrt.Context(device=0, flags=mrt.FLAG_FULL_TEST)
+    try:
+        ref, out = _both(mrt, ctx, sc.with_resolution(4000, 2300), 2300, 0, 1)
+        assert np.array_equal(out, ref)
+    finally:
+        ctx.close()
     # beyond the fixed array: 7680 x 4320 needs 33.4 M keys, the array holds 8 M
     ctx = mrt.Context(device=0)
     try:
