@@ -236,8 +236,10 @@ int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uin
  * hipMalloc / hipFree (nor any other allocating call).  The array holds
  * MRT_NOALLOC_MAX_KEYS 64-bit keys (64 MiB on every GPU the library has been
  * used on, until the process ends): the rows this rank renders, padded to
- * whole 64x64 pixel tiles, must fit -- a 3840x2160 frame does -- or the call
- * fails with MRT_ERR_TOO_LARGE.  Every call on
+ * whole block tiles (64x64 pixels, 128x64 for frames of 4 Mpixel and more),
+ * must fit -- a 3840x2160 frame does -- or the call fails with
+ * MRT_ERR_TOO_LARGE (a MRT_FLAG_FULL_TEST context, whose kernel only merges
+ * its layers in the key plane, then runs as one layer instead).  Every call on
  * one GPU, from whatever ctx, shares that GPU's array: two such frames in
  * flight at once on one GPU race; enqueue them on one stream or synchronise
  * between them.  No counterpart in the reference, which allocates in every
