@@ -1352,8 +1352,10 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                     }
                 }
                 // a quantity that is NaN (non-finite rays) may go either way, no such pair is a hit
+                // (the compare's lane mask itself is the vote: no round trip through a VGPR)
+                const uint64_t cand_mask = __builtin_amdgcn_uicmp(neg, 0u, 32 /* ICMP_EQ */);
+                if (cand_mask == 0) continue;
                 const bool cand = neg == 0u;
-                if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
                 if (cand) {
                     const uint32_t ti = __builtin_amdgcn_readfirstlane(s_ids[g]);
                     const float4 va = p.tri_exact[(size_t)ti * 3 + 0];
