@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                 // has the sign bit set, and `neg` keeps the sign bit only while every pixel of the
                 // lane has been ruled out.  A quantity that could belong to an accepted pair is
                 // at least half its (positive) margin, so -0 never stands for "not negative".
-                uint32_t neg = 0x80000000u;
+                uint32_t neg = 0xFFFFFFFFu;              // only the sign bit is ever looked at
                 if (PROJ == MRT_PROJ_PERSP) {
                     const F3 s2 = mk3(q0.x, q0.y, q0.z), sol = mk3(q1.x, q1.y, q1.z);
                     const F3 e = mk3(q2.x, q2.y, q2.z), s1 = mk3(q3.x, q3.y, q3.z);
@@ -1353,9 +1353,9 @@ __global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderP
                 }
                 // a quantity that is NaN (non-finite rays) may go either way, no such pair is a hit
                 // (the compare's lane mask itself is the vote: no round trip through a VGPR)
-                const uint64_t cand_mask = __builtin_amdgcn_uicmp(neg, 0u, 32 /* ICMP_EQ */);
+                const uint64_t cand_mask = __builtin_amdgcn_sicmp((int32_t)neg, -1, 38 /* ICMP_SGT */);
                 if (cand_mask == 0) continue;
-                const bool cand = neg == 0u;
+                const bool cand = (int32_t)neg > -1;
                 if (cand) {
                     const uint32_t ti = __builtin_amdgcn_readfirstlane(s_ids[g]);
                     const float4 va = p.tri_exact[(size_t)ti * 3 + 0];
