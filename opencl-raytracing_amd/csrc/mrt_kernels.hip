@@ -253,7 +253,11 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     __shared__ float4 s_rec[kChunkFloat4];
     __shared__ float4 s_circ[kChunkTris];
     // per wave: the pixels one primitive still has to be tested on, and the tile's uv components
-    __shared__ uint16_t s_list[kBlockThreads / 64][kTrTileX * kTrTileY];
+    // (the pixel list holds 16 pixels per lane: a larger lane block is listed and tested in parts
+    // of 16 / LX rows, which keeps the kernel's LDS at six blocks per CU for either shape)
+    constexpr int kListRows = 16 / kTrLaneX, kListParts = kTrLaneY / kListRows;
+    static_assert(kListRows >= 1 && kTrLaneY % kListRows == 0, "whole rows per part");
+    __shared__ uint16_t s_list[kBlockThreads / 64][64 * 16];
     __shared__ float s_ux[kBlockThreads / 64][kTrTileX], s_uy[kBlockThreads / 64][kTrTileY];
     // one bit per pixel of the lane's block, bit j * kTrLaneX + i = row j, column i
     using Mask = typename std::conditional<(kTrLaneX * kTrLaneY > 32), unsigned long long, uint32_t>::type;
@@ -372,8 +376,13 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                 }
                 if (no_prefilter) mask = kAllPixels;
                 if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
-                const uint32_t total = list_pixels<kTrLaneX, kTrTileX, Mask>(mask, bx, by, lane, list, list_count);
-                exact_list<PROJ, false, kTrTileX>(p, si, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact, recorded);
+#pragma unroll
+                for (int part = 0; part < kListParts; ++part) {
+                    const uint32_t bits = (uint32_t)(mask >> (part * 16)) & 0xFFFFu;
+                    if (kListParts > 1 && __builtin_amdgcn_ballot_w64(bits != 0) == 0) continue;
+                    const uint32_t total = list_pixels<kTrLaneX, kTrTileX>(bits, bx, by + part * kListRows, lane, list, list_count);
+                    exact_list<PROJ, false, kTrTileX>(p, si, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact, recorded);
+                }
             }
         }
     }
@@ -508,8 +517,13 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
                 }
                 if (no_prefilter) mask = kAllPixels;
                 if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
-                const uint32_t total = list_pixels<kTrLaneX, kTrTileX, Mask>(mask, bx, by, lane, list, list_count);
-                exact_list<PROJ, true, kTrTileX>(p, ti, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact, recorded);
+#pragma unroll
+                for (int part = 0; part < kListParts; ++part) {
+                    const uint32_t bits = (uint32_t)(mask >> (part * 16)) & 0xFFFFu;
+                    if (kListParts > 1 && __builtin_amdgcn_ballot_w64(bits != 0) == 0) continue;
+                    const uint32_t total = list_pixels<kTrLaneX, kTrTileX>(bits, bx, by + part * kListRows, lane, list, list_count);
+                    exact_list<PROJ, true, kTrTileX>(p, ti, total, lane, list, tile_ux, tile_uy, tile_keys, pitch, n_exact, recorded);
+                }
             }
         }
         }

@@ -62,7 +62,9 @@ constexpr int kGroupCircle = MRT_GROUP_CIRCLE;   // triangles per vote of the bo
 
 // Register budget of trace_kernel in waves per SIMD.  6 (<= 80 VGPRs) is what
 // the kernel needs without spilling in its hot loop; 7 measured the same and 8
-// (64 VGPRs, spills) 7 % slower on teatime 4K.
+// (64 VGPRs, spills) 7 % slower on teatime 4K.  The 8x4 shape would take 98
+// VGPRs; held to 80 it spills 19 outside the hot loop and is 2-3 % faster at
+// six waves per SIMD than at four (five: the same as six).
 #ifndef MRT_TRACE_WAVES_PER_SIMD
 #define MRT_TRACE_WAVES_PER_SIMD 6
 #endif
