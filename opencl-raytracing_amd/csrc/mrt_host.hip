@@ -399,8 +399,9 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     p.tile_flags = nullptr;
     p.tiles_x = pitch / tile_x;
     p.tile_x_log2 = wide ? 6u : 5u;
-    p.tile_y_log2 = 5u;
-    static_assert(mrt::TraceWide::tile_x == 64 && mrt::TraceNarrow::tile_x == 32 && mrt::TraceWide::tile_y == 32 && mrt::TraceNarrow::tile_y == 32, "tile sizes as shifts");
+    p.tile_y_log2 = (wide && mrt::TraceWide::tile_y == 64) ? 6u : 5u;
+    static_assert(mrt::TraceWide::tile_x == 64 && mrt::TraceNarrow::tile_x == 32 && mrt::TraceNarrow::tile_y == 32 &&
+                      (mrt::TraceWide::tile_y == 32 || mrt::TraceWide::tile_y == 64), "tile sizes as shifts");
     const bool keeps_keys_clean = p.prim_slices > 1 && planes.own;
     if (keeps_keys_clean) {
         // The ctx's own key plane stays all "no hit" from frame to frame: shade_keys_kernel puts
@@ -436,7 +437,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else if (persp && wide) {
         kernel = MRT_KERNEL_TRACE_WIDE;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, 8, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, mrt::TraceWide::lane_x, mrt::TraceWide::lane_y>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else if (persp) {
         kernel = MRT_KERNEL_TRACE;
         hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
@@ -445,7 +446,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else if (wide) {
         kernel = MRT_KERNEL_TRACE_WIDE;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, 8, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, mrt::TraceWide::lane_x, mrt::TraceWide::lane_y>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else {
         kernel = MRT_KERNEL_TRACE;
         hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);

@@ -1485,8 +1485,8 @@ __global__ __launch_bounds__(256) void shade_kernel(const RenderParams p,
 
 template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_PERSP, false, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, 8, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_PERSP, false, 8, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, TraceWide::lane_x, TraceWide::lane_y>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, false, TraceWide::lane_x, TraceWide::lane_y>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_ORTHO, true, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void trace_kernel<MRT_PROJ_PERSP, true, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void full_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, unsigned long long*, float*, int32_t*, uint32_t);

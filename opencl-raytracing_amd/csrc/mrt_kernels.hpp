@@ -34,7 +34,10 @@ struct TraceShape {
     static constexpr int block_x = tile_x * kBlockWavesX, block_y = tile_y * kBlockWavesY;
 };
 using TraceNarrow = TraceShape<4, 4>;      // 32 x 32 tiles, 64 x 64 blocks
-using TraceWide = TraceShape<8, 4>;        // 64 x 32 tiles, 128 x 64 blocks
+#ifndef MRT_WIDE_LANE_Y
+#define MRT_WIDE_LANE_Y 4                  // (8 builds the 8x8 shape in its place, for measurements)
+#endif
+using TraceWide = TraceShape<8, MRT_WIDE_LANE_Y>;        // 64 x 32 tiles, 128 x 64 blocks
 
 // Prefilter records are staged through LDS in chunks of kChunkFloat4 float4
 // (12 KiB): 256 triangle records of three float4, or 768 sphere records of
