@@ -1216,7 +1216,7 @@ __global__ void prep_full_records(const RenderParams p, float4* __restrict__ rec
 }
 
 template <int PROJ>
-__global__ __launch_bounds__(kBlockThreads) void full_trace_kernel(const RenderParams p,
+__global__ __launch_bounds__(kBlockThreads, MRT_FULL_WAVES_PER_SIMD) void full_trace_kernel(const RenderParams p,
                                                                   const float4* __restrict__ full_rec,
                                                                   const uint32_t* __restrict__ full_ids,
                                                                   const uint32_t* __restrict__ class_counts,

@@ -49,6 +49,9 @@ constexpr int kFullRecFloat4 = 4;          // float4 per triangle record of full
 #ifndef MRT_FULL_PX_Y
 #define MRT_FULL_PX_Y 2
 #endif
+#ifndef MRT_FULL_WAVES_PER_SIMD
+#define MRT_FULL_WAVES_PER_SIMD 4
+#endif
 constexpr int kFullPxX = 4, kFullPxY = MRT_FULL_PX_Y, kFullSlots = kFullPxX * kFullPxY;
 constexpr int kFullWaveH = 8 * kFullPxY;          // 16 rows per wave
 constexpr int kFullBlockH = 2 * kFullWaveH;       // 32 rows per block
