@@ -130,6 +130,7 @@ struct mrt_ctx {
     // another stream can be ordered after it (the working planes above are shared by all frames).
     uint32_t last_kernel = MRT_KERNEL_TRACE, last_slices = 1;
     uint32_t last_pitch = 0;                 // pitch of the (t, id) planes the last frame wrote
+    uint32_t frame_tag = 0;                  // tag of the last frame that used the tile flags
     // mrt_stage_*: device staging buffers that grow on demand and live as long as the ctx
     void* stage_buf[3] = {nullptr, nullptr, nullptr};
     size_t stage_cap[3] = {0, 0, 0};
@@ -230,6 +231,9 @@ int ensure_keys(mrt_ctx* ctx, size_t elems) {
         if (ctx->d_tile_flags) { (void)hipFree(ctx->d_tile_flags); ctx->d_tile_flags = nullptr; }
         ctx->tile_flag_elems = 0;
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_flags, tiles * sizeof(uint32_t)));
+        // no frame's tag; done before any stream uses the new buffer (growth is rare)
+        HIP_TRY(ctx, hipMemset(ctx->d_tile_flags, 0, tiles * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipDeviceSynchronize());
         ctx->tile_flag_elems = tiles;
     }
     return MRT_OK;
@@ -410,8 +414,13 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         if (!ctx->keys_clean)
             HIP_TRY(ctx, hipMemsetAsync(d_key, 0xFF, ctx->key_elems * sizeof(unsigned long long), stream));
         ctx->keys_clean = false;               // until this frame's shade_keys_kernel is enqueued
+        // The tile flags carry a tag per frame instead of being cleared per frame.
         p.tile_flags = ctx->d_tile_flags;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_flags, 0, plane_elems / ((size_t)tile_x * tile_y) * sizeof(uint32_t), stream));
+        if (++ctx->frame_tag == 0) {          // wrapped after 2^32 frames: start over from clean flags
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_flags, 0, ctx->tile_flag_elems * sizeof(uint32_t), stream));
+            ctx->frame_tag = 1;
+        }
+        p.frame_tag = ctx->frame_tag;
     } else if (p.prim_slices > 1) {
         HIP_TRY(ctx, hipMemsetAsync(d_key, 0xFF, plane_elems * sizeof(unsigned long long), stream));
     } else if (d_key != nullptr && planes.own) {

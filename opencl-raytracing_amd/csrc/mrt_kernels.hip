@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     if (wave_active && !single_slice) {
         // tell shade_keys_kernel that this tile has keys worth reading (any wave of any slice may)
         if (p.tile_flags != nullptr && recorded && lane == 0)
-            p.tile_flags[(wave_lr0 / kTrTileY) * p.tiles_x + wave_x0 / kTrTileX] = 1u;
+            p.tile_flags[(wave_lr0 / kTrTileY) * p.tiles_x + wave_x0 / kTrTileX] = p.frame_tag;
         if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
     } else if (wave_active) {
         // The atomics went to the device's L2; make sure the loads below see them.
@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_FULL_WAVES_PER_SIMD) void full_t
             }
         }
         if (p.tile_flags != nullptr && __builtin_amdgcn_ballot_w64(rec) != 0 && lane == 0)
-            p.tile_flags[(wave_lr0 >> p.tile_y_log2) * p.tiles_x + (wave_x0 >> p.tile_x_log2)] = 1u;
+            p.tile_flags[(wave_lr0 >> p.tile_y_log2) * p.tiles_x + (wave_x0 >> p.tile_x_log2)] = p.frame_tag;
         if (p.exact_counter != nullptr && layer == 0)
             atomicAdd(p.exact_counter, (unsigned long long)kFullSlots * ((unsigned long long)p.n_sph + p.n_tri));
     } else if (wave_active) {
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(256) void shade_keys_kernel(const RenderParams p,
     unsigned long long key = ~0ull;
     if (p.tile_flags == nullptr) {
         key = key_plane[src];
-    } else if (p.tile_flags[(lr >> p.tile_y_log2) * p.tiles_x + (x >> p.tile_x_log2)] != 0u) {
+    } else if (p.tile_flags[(lr >> p.tile_y_log2) * p.tiles_x + (x >> p.tile_x_log2)] == p.frame_tag) {
         key = key_plane[src];
         if (key != ~0ull) key_plane[src] = ~0ull;
     }

@@ -105,10 +105,13 @@ struct RenderParams {
     int32_t* ids;                   // optional, local_rows x xres
     float* tvals;                   // optional
     unsigned long long* exact_counter;  // optional
-    // Sliced trace_kernel frames with ctx-owned planes: one word per wave tile, set by any
-    // wave that recorded a hit there, so that shade_keys_kernel reads (and puts back to "no hit")
-    // only the keys of tiles something hit.  nullptr: every key is read and none is put back.
+    // Sliced trace_kernel frames with ctx-owned planes: one word per wave tile, set to this
+    // frame's tag by any wave that recorded a hit there, so that shade_keys_kernel reads (and puts
+    // back to "no hit") only the keys of tiles something hit.  A word that holds another frame's
+    // tag means "nothing hit", so the flags are never cleared between frames.  nullptr: every key
+    // is read and none is put back.
     uint32_t* tile_flags;
+    uint32_t frame_tag;             // never 0 (what a fresh flag buffer holds)
     uint32_t tiles_x;               // trace_kernel wave tiles per row of the padded plane
     uint32_t tile_x_log2, tile_y_log2;  // ... and their size (32 x 32 or 64 x 32)
 };
