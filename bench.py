@@ -12,7 +12,11 @@ grows to 3840 x (2160*N) with the viewport's top/bottom scaled by N, so every
 rank still renders 2160 rows' worth of interleaved 64-row bands ("weak"
 scaling: fixed work per GPU), and every step gathers all bands to rank 0 over
 RCCL; the gather of frame k runs on RCCL's stream while frame k+1 renders (two
-buffer sets).
+buffer sets per frame in flight).  The headline keeps FRAMES_IN_FLIGHT = 2
+frames enqueued side by side, each on an mrt_ctx and a stream of its own, in
+rotation (a 4K frame alone leaves SIMDs idle while its last waves drain and the
+next frame's first ones start); the same K steps with one frame at a time are
+the one_frame_in_flight_* keys.
 
 Rank 0 prints ONE JSON line.  `value` is the throughput of the library's default path
 (trace_kernel: every ray x every primitive, most pairs settled by a conservative per-pixel
@@ -49,6 +53,7 @@ FP32_PEAK_TFLOPS = 157.3          # 256 CU x 128 lanes x 2 FLOP x 2.4 GHz
 VALU_ISSUE_PEAK = 78.6e12         # lane-ops/s: 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
 BAND_ROWS = 64
 XRES, YRES = 3840, 2160
+FRAMES_IN_FLIGHT = 2              # headline: frames enqueued side by side (a context and a stream each)
 
 
 def algorithmic_flops(st, rays):
@@ -113,39 +118,50 @@ class Job:
     """One process-per-GPU render job: this rank's interleaved bands of one scene, gathered to
     rank 0.  Two buffer sets, so the gather of frame k overlaps the render of frame k+1."""
 
-    def __init__(self, env, scene, flags=0):
-        """flags: MRT_FLAG_* of a brute-force context, or the name of an mrt_accel method."""
+    def __init__(self, env, scene, flags=0, in_flight=1):
+        """flags: MRT_FLAG_* of a brute-force context, or the name of an mrt_accel method.
+        in_flight: frames enqueued side by side, each on a context and a stream of its own (a
+        context's working planes serve one frame at a time), handed out in rotation: the GPU then
+        starts a frame while the last waves of the one before drain."""
         import torch
         self.env, self.scene = env, scene
         st = scene.struct
         self.st = st
-        self.ctx = env.mrt.renderer(device=env.dev_index, kind=flags)
-        self.ctx.set_scene(scene)
+        self.in_flight = in_flight
+        self.ctxs = [env.mrt.renderer(device=env.dev_index, kind=flags) for _ in range(in_flight)]
+        for c in self.ctxs:
+            c.set_scene(scene)
+        self.ctx = self.ctxs[0]
+        self.streams = [env.stream] if in_flight == 1 else [torch.cuda.Stream(env.dev) for _ in range(in_flight)]
         mrt, world = env.mrt, env.world
         self.rows = mrt.band_rows(st.yres, BAND_ROWS, env.rank, world)
         nbytes = max(mrt.band_rows(st.yres, BAND_ROWS, r, world) for r in range(world)) * st.xres * 4
-        self.local = [torch.empty(nbytes, dtype=torch.uint8, device=env.dev) for _ in range(2)]
+        # two buffer sets per frame in flight: the gather of a frame overlaps the next frame of its slot
+        self.n_sets = 2 * in_flight
+        self.local = [torch.empty(nbytes, dtype=torch.uint8, device=env.dev) for _ in range(self.n_sets)]
         self.gathered = [([torch.empty(nbytes, dtype=torch.uint8, device=env.gdev) for _ in range(world)]
-                          if (env.use_dist and env.rank == 0) else None) for _ in range(2)]
-        self.works = [None, None]
+                          if (env.use_dist and env.rank == 0) else None) for _ in range(self.n_sets)]
+        self.works = [None] * self.n_sets
 
     def step(self, k):
-        env, b = self.env, k & 1
-        if self.works[b] is not None:
-            self.works[b].wait()     # stream-level wait: frame k-2's gather is done with buffer b
-            self.works[b] = None
-        self.ctx.render_bands_device(BAND_ROWS, env.rank, env.world, self.local[b].data_ptr(),
-                                     self.local[b].numel(), stream=env.stream.cuda_stream)
-        if env.use_dist:
-            if env.rehearsal:
-                env.dist.gather(self.local[b].cpu(), self.gathered[b], dst=0)
-            else:
-                self.works[b] = env.dist.gather(self.local[b], self.gathered[b], dst=0, async_op=True)
+        import torch
+        env, b, f = self.env, k % self.n_sets, k % self.in_flight
+        with torch.cuda.stream(self.streams[f]):
+            if self.works[b] is not None:
+                self.works[b].wait()     # stream-level wait: the last gather out of buffer b is done
+                self.works[b] = None
+            self.ctxs[f].render_bands_device(BAND_ROWS, env.rank, env.world, self.local[b].data_ptr(),
+                                             self.local[b].numel(), stream=self.streams[f].cuda_stream)
+            if env.use_dist:
+                if env.rehearsal:
+                    env.dist.gather(self.local[b].cpu(), self.gathered[b], dst=0)
+                else:
+                    self.works[b] = env.dist.gather(self.local[b], self.gathered[b], dst=0, async_op=True)
 
     def fence(self):
         import torch
         env = self.env
-        for b in range(2):
+        for b in range(self.n_sets):
             if self.works[b] is not None:
                 self.works[b].wait()
                 self.works[b] = None
@@ -190,7 +206,8 @@ class Job:
         return sum(tr) / len(tr), sum(sh) / len(sh)
 
     def close(self):
-        self.ctx.close()
+        for c in self.ctxs:
+            c.close()
         self.local = self.gathered = None
 
 
@@ -427,8 +444,17 @@ def main():
     if world > 1:
         sc = sc.with_resolution(XRES, YRES * world, top=float(world), bottom=-float(world))
     st = sc.struct
-    job = Job(env, sc)
+    # Three timed regions of K steps back to back, each with its own W warmup steps: one frame at
+    # a time on a GPU that has been idle (its clock climbs for the first 25 ms or so of work: the
+    # cold_start_* keys), the headline with two frames in flight (a context and a stream each, in
+    # rotation, so that the head of a frame fills the SIMDs the draining tail of the one before
+    # leaves idle), and one frame at a time again, now warm (one_frame_in_flight_*).
+    job1 = Job(env, sc)
+    job = Job(env, sc, in_flight=FRAMES_IN_FLIGHT)
+    elapsed_cold = job1.timed(args.steps, args.warmup)
     elapsed = job.timed(args.steps, args.warmup)
+    elapsed_one = job1.timed(args.steps, args.warmup)
+    job1.close()
     trace_avg, shade_avg = job.kernel_ms(max(10, min(args.steps, 50)))
     host = host_frame(env, job, st.xres * st.yres) if (world == 1 and rank == 0) else None
     job.close()
@@ -461,12 +487,18 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "teatime_4k" if world == 1 else f"teatime_3840x{st.yres}_bands{BAND_ROWS}",
                        "xres": st.xres, "yres": st.yres, "rays_per_step": total_rays,
-                       "primitives": n_prims, "band_rows": BAND_ROWS,
+                       "primitives": n_prims, "band_rows": BAND_ROWS, "frames_in_flight": FRAMES_IN_FLIGHT,
                        "gather": ("none" if not env.use_dist else
                                   "REHEARSAL: all ranks on GPU 0, gloo gather through host memory"
                                   if env.rehearsal else "rccl gather to rank 0, overlapped with the next frame"),
                        "output": "RGBA8 resident in HBM (no D2H in the timed region)"},
             "prim_tests_per_s": value * 1e6 * n_prims,
+            # the same K steps with one frame in flight (one context, one stream)
+            "one_frame_in_flight_ms_per_step": elapsed_one / args.steps * 1e3,
+            "one_frame_in_flight_mrays_per_s": total_rays * args.steps / elapsed_one * 1e-6,
+            # ... and on a GPU that was idle before the W warmup steps
+            "cold_start_ms_per_step": elapsed_cold / args.steps * 1e3,
+            "cold_start_mrays_per_s": total_rays * args.steps / elapsed_cold * 1e-6,
             "roofline": {
                 "bound": "valu", "kernel": "full_trace_kernel", "kernel_ms": full_trace,
                 "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

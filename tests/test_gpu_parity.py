@@ -627,6 +627,39 @@ def test_render_is_deterministic(gpu_ctx, mrt):
         gpu_ctx.render(out=np.empty((10, 10, 4), np.uint8))
 
 
+def test_frames_in_flight_on_two_contexts(gpu_ctx, mrt):
+    """Frames enqueued side by side, each on a context and a stream of its own (how bench.py keeps
+    two frames in flight): every frame equals the frame one context renders alone, also when the
+    two contexts hold different views."""
+    import torch
+    xres, yres = 1920, 1080
+    views = [mrt.LoadedScene(text=mkscene.teatime(xres, yres)).copy(),
+             mrt.LoadedScene(text=mkscene.teatime(xres, yres)).copy().with_resolution(
+                 xres, yres, left=-1.0, right=1.5, top=0.7, bottom=-0.9)]
+    want = []
+    for sc in views:
+        gpu_ctx.set_scene(sc)
+        want.append(gpu_ctx.render()[0])
+    ctxs = [mrt.Context(device=0) for _ in views]
+    try:
+        streams = [torch.cuda.Stream() for _ in views]
+        bufs = [[torch.zeros(xres * yres * 4, dtype=torch.uint8, device="cuda:0") for _ in range(6)] for _ in views]
+        for c, sc in zip(ctxs, views):
+            c.set_scene(sc)
+        torch.cuda.synchronize()
+        for k in range(6):
+            for f, c in enumerate(ctxs):
+                c.render_bands_device(64, 0, 1, bufs[f][k].data_ptr(), bufs[f][k].numel(),
+                                      stream=streams[f].cuda_stream)
+        torch.cuda.synchronize()
+        for f in range(len(views)):
+            for k in range(6):
+                assert np.array_equal(bufs[f][k].cpu().numpy().reshape(yres, xres, 4), want[f]), (f, k)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 @pytest.mark.parametrize("shape", ["narrow", "wide"])
 @pytest.mark.parametrize("world,band", [(2, 64), (3, 16), (8, 64), (4, 7)])
 def test_band_partition_invariance(gpu_ctx, mrt, world, band, shape):
