@@ -242,8 +242,13 @@ int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uin
  * its layers in the key plane, then runs as one layer instead).  Every call on
  * one GPU, from whatever ctx, shares that GPU's array: two such frames in
  * flight at once on one GPU race; enqueue them on one stream or synchronise
- * between them.  No counterpart in the reference, which allocates in every
- * stage call (CLHelpers.hpp:93-104). */
+ * between them.  Not allocating is all it promises: replaying a call from a
+ * captured HIP graph is NOT supported -- the one attempt made (a call captured
+ * with torch.cuda.graph and replayed) ended in a GPU memory fault whose cause
+ * was not found, and the per-frame state the call keeps on the host (which
+ * buffers are clean, the pending per-view records) is not part of a graph.
+ * No counterpart in the reference, which allocates in every stage call
+ * (CLHelpers.hpp:93-104). */
 #define MRT_NOALLOC_MAX_KEYS (8u * 1024u * 1024u)
 int mrt_render_bands_device_noalloc(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uint32_t world,
                                     void *dev_out, size_t dev_out_bytes, void *hip_stream);
