@@ -23,88 +23,91 @@ using jsonmin::Value;
 
 namespace {
 
-struct ReadError { std::string message; };
+// A scene file that the schema rejects; the message is what the caller sees.
+struct Rejected { std::string message; };
 
 struct Vec3 { double x = 0, y = 0, z = 0; };
-inline bool same(const Vec3& a, const Vec3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
 
-bool has(const Value& obj, const std::string& key) { return obj.find(key) != nullptr; }
+// What a float-typed field has to satisfy beyond being a float token.
+enum class Range { Any, Positive, Negative, NonNegative };
 
-const Value& need(const Value& obj, const std::string& key) {
-    const Value* v = obj.find(key);
-    if (!v) throw ReadError{"missing key \"" + key + "\""};      // rayson.hpp:390-394
-    return *v;
-}
+// One JSON object seen through the scene schema.  Every accessor checks
+// presence first, then the token type, then the range, and rejects with the
+// message the reference gives for that failure (rayson.hpp:390-487).
+class Fields {
+public:
+    explicit Fields(const Value& object) : obj_(object) {}
 
-bool get_bool(const Value& obj, const std::string& key) {
-    const Value& v = need(obj, key);
-    if (!v.is_boolean()) throw ReadError{"key \"" + key + "\" must be a bool"};   // :396-402
-    return v.b;
-}
+    bool present(const char* key) const { return obj_.find(key) != nullptr; }
+    const Value* child(const char* key) const { return obj_.find(key); }
 
-double get_double(const Value& obj, const std::string& key) {
-    const Value& v = need(obj, key);
-    // Only float-typed tokens pass: 20 is rejected where 20.0 is accepted (:404-410).
-    if (!v.is_number_float()) throw ReadError{"key \"" + key + "\" must be a float"};
-    return v.d;
-}
-
-std::string get_string(const Value& obj, const std::string& key) {
-    const Value& v = need(obj, key);
-    if (!v.is_string()) throw ReadError{"key \"" + key + "\" must be a string"};  // :412-418
-    return v.s;
-}
-
-unsigned get_positive_unsigned(const Value& obj, const std::string& key) {
-    const Value& v = need(obj, key);
-    if (!v.is_number_integer()) throw ReadError{"key \"" + key + "\" must be an integer"};  // :420-430
-    int x = (v.kind == jsonmin::Kind::Int) ? static_cast<int>(v.i) : static_cast<int>(v.u);
-    if (x <= 0) throw ReadError{"key \"" + key + "\" must be positive"};
-    return static_cast<unsigned>(x);
-}
-
-Vec3 get_vector3(const Value& obj, const std::string& key) {
-    const Value& a = need(obj, key);
-    if (!a.is_array()) throw ReadError{"expected " + key + " to be an array"};     // :435-437
-    if (a.size() != 3) {
-        // The count reported is the size of the enclosing object, as at :438-441.
-        throw ReadError{"expected array " + key + " to have 3 elements, but found " +
-                        std::to_string(obj.size()) + " elements"};
+    bool flag(const char* key) const {
+        const Value& v = at(key);
+        if (!v.is_boolean()) reject(quoted(key) + " must be a bool");               // :396-402
+        return v.b;
     }
-    bool ok0, ok1, ok2;
-    Vec3 r;
-    r.x = a.items[0].as_double(ok0);
-    r.y = a.items[1].as_double(ok1);
-    r.z = a.items[2].as_double(ok2);
-    if (!(ok0 && ok1 && ok2)) throw ReadError{"vector3 must contain numbers"};     // :442-448
-    return r;
-}
+    // Only float-typed tokens pass: 20 is rejected where 20.0 is accepted (:404-410, :451-473).
+    double real(const char* key, Range range = Range::Any) const {
+        const Value& v = at(key);
+        if (!v.is_number_float()) reject(quoted(key) + " must be a float");
+        const double x = v.d;
+        switch (range) {
+            case Range::Positive:    if (x <= 0.0) reject(quoted(key) + " must be positive"); break;
+            case Range::Negative:    if (x >= 0.0) reject(quoted(key) + " must be negative"); break;
+            case Range::NonNegative: if (x < 0.0) reject(quoted(key) + " must be non-negative"); break;
+            case Range::Any: break;
+        }
+        return x;
+    }
+    std::string text(const char* key) const {
+        const Value& v = at(key);
+        if (!v.is_string()) reject(quoted(key) + " must be a string");               // :412-418
+        return v.s;
+    }
+    unsigned count(const char* key) const {                                          // :420-430
+        const Value& v = at(key);
+        if (!v.is_number_integer()) reject(quoted(key) + " must be an integer");
+        const int x = (v.kind == jsonmin::Kind::Int) ? static_cast<int>(v.i) : static_cast<int>(v.u);
+        if (x <= 0) reject(quoted(key) + " must be positive");
+        return static_cast<unsigned>(x);
+    }
+    Vec3 vec3(const char* key) const {                                               // :432-449
+        const Value& a = at(key);
+        if (!a.is_array()) reject(std::string("expected ") + key + " to be an array");
+        // the count reported is the size of the enclosing object, as at :438-441
+        if (a.size() != 3)
+            reject(std::string("expected array ") + key + " to have 3 elements, but found " +
+                   std::to_string(obj_.size()) + " elements");
+        double c[3];
+        bool all = true;
+        for (int k = 0; k < 3; ++k) {
+            bool ok = false;
+            c[k] = a.items[k].as_double(ok);
+            all = all && ok;
+        }
+        if (!all) reject("vector3 must contain numbers");
+        return Vec3{c[0], c[1], c[2]};
+    }
+    Vec3 color(const char* key) const {                                              // :475-487
+        const Vec3 c = vec3(key);
+        const double comp[3] = {c.x, c.y, c.z};
+        for (int k = 0; k < 3; ++k)
+            if (comp[k] < 0.0 || comp[k] > 1.0)
+                reject(std::string("color has ") + "rgb"[k] + " component outside the range [0, 1]");
+        return c;
+    }
 
-double get_positive_double(const Value& obj, const std::string& key) {
-    double x = get_double(obj, key);
-    if (x <= 0.0) throw ReadError{"key \"" + key + "\" must be positive"};         // :451-457
-    return x;
-}
-double get_negative_double(const Value& obj, const std::string& key) {
-    double x = get_double(obj, key);
-    if (x >= 0.0) throw ReadError{"key \"" + key + "\" must be negative"};         // :459-465
-    return x;
-}
-double get_nonnegative_double(const Value& obj, const std::string& key) {
-    double x = get_double(obj, key);
-    if (x < 0.0) throw ReadError{"key \"" + key + "\" must be non-negative"};      // :467-473
-    return x;
-}
+    [[noreturn]] static void reject(const std::string& message) { throw Rejected{message}; }
 
-Vec3 get_color(const Value& obj, const std::string& key) {
-    Vec3 c = get_vector3(obj, key);                                                 // :475-487
-    if (c.x < 0.0 || c.x > 1.0) throw ReadError{"color has r component outside the range [0, 1]"};
-    if (c.y < 0.0 || c.y > 1.0) throw ReadError{"color has g component outside the range [0, 1]"};
-    if (c.z < 0.0 || c.z > 1.0) throw ReadError{"color has b component outside the range [0, 1]"};
-    return c;
-}
-
-struct Material { std::string name; double shininess; Vec3 color; };
+private:
+    static std::string quoted(const char* key) { return std::string("key \"") + key + "\""; }
+    const Value& at(const char* key) const {
+        const Value* v = obj_.find(key);
+        if (!v) reject(std::string("missing ") + quoted(key));                       // :390-394
+        return *v;
+    }
+    const Value& obj_;
+};
 
 }  // namespace
 
@@ -123,200 +126,164 @@ struct mrt_loaded_scene {
 
 namespace {
 
-void build(const Value& j, mrt_loaded_scene& out) {
-    if (!j.is_object()) throw ReadError{"rayson must be comprised of one JSON object"};  // :382-384
+template <size_t N>
+void append(std::vector<float> (&planes)[N], size_t first, const Vec3& v) {
+    planes[first + 0].push_back(static_cast<float>(v.x));
+    planes[first + 1].push_back(static_cast<float>(v.y));
+    planes[first + 2].push_back(static_cast<float>(v.z));
+}
 
-    // camera, rayson.hpp:489-491
-    Vec3 eye = get_vector3(j, "camera_eye");
-    Vec3 up = get_vector3(j, "camera_up");
-    Vec3 view = get_vector3(j, "camera_view");
+void store3(float (&dst)[3], const double (&src)[3]) {
+    for (int k = 0; k < 3; ++k) dst[k] = static_cast<float>(src[k]);
+}
 
-    // viewport, :493-498
-    unsigned xres = get_positive_unsigned(j, "x_resolution");
-    unsigned yres = get_positive_unsigned(j, "y_resolution");
-    double left = get_negative_double(j, "viewport_left");
-    double top = get_positive_double(j, "viewport_top");
-    double right = get_positive_double(j, "viewport_right");
-    double bottom = get_negative_double(j, "viewport_bottom");
+// The element objects of an optional or required list, in file order.
+std::vector<const Value*> elements(const Fields& scene, const char* key) {
+    const Value* list = scene.child(key);
+    return list ? list->children() : std::vector<const Value*>();
+}
 
-    // projection, :500-521
-    int projection = MRT_PROJ_ORTHO;
-    double focal = 0.0;
-    {
-        const std::string ortho_key = "ortho_projection", persp_key = "persp_focal_length";
-        bool has_orth = has(j, ortho_key), has_persp = has(j, persp_key);
-        if (has_orth && has_persp) throw ReadError{"cannot have both " + ortho_key + " and " + persp_key};
-        if (!has_orth && !has_persp) throw ReadError{"must have " + ortho_key + " or " + persp_key};
-        if (has_orth) {
-            if (!get_bool(j, ortho_key)) throw ReadError{ortho_key + ", if present, must be true"};
-            projection = MRT_PROJ_ORTHO;
-        } else {
-            projection = MRT_PROJ_PERSP;
-            focal = get_positive_double(j, persp_key);
-        }
-    }
-
-    // shader, :523-540 (flat_shader wins when both are present)
-    int shader = MRT_SHADER_FLAT;
-    double ka = 0, kd = 0, ks = 0;
-    Vec3 amb;
-    if (has(j, "flat_shader")) {
-        if (!get_bool(j, "flat_shader")) throw ReadError{"flat_shader, if present, must be true"};
-    } else if (has(j, "phong_shader")) {
-        const Value& child = *j.find("phong_shader");
-        shader = MRT_SHADER_PHONG;
-        ka = get_nonnegative_double(child, "ambient_coeff");
-        kd = get_nonnegative_double(child, "diffuse_coeff");
-        ks = get_nonnegative_double(child, "specular_coeff");
-        amb = get_color(child, "ambient_color");
-    } else {
-        throw ReadError{"must have flat_shader or phong_shader"};
-    }
-
-    Vec3 background = get_color(j, "background");                                   // :542
-
-    // point lights (optional), :550-560
-    struct Light { Vec3 loc, color; double intensity; };
-    std::vector<Light> lights;
-    if (has(j, "point_lights")) {
-        const Value& child = *j.find("point_lights");
-        if (!child.is_array()) throw ReadError{"expected point_lights to be an array"};
-        for (const Value* it : child.children()) {
-            Light l;
-            l.loc = get_vector3(*it, "location");
-            l.color = get_color(*it, "color");
-            l.intensity = get_positive_double(*it, "intensity");
-            lights.push_back(l);
-        }
-    }
-
-    // materials (required), :562-581
-    std::vector<Material> materials;
-    if (!has(j, "materials")) throw ReadError{"no materials list"};
-    for (const Value* it : j.find("materials")->children()) {
-        Material m;
-        m.name = get_string(*it, "name");
-        m.shininess = get_positive_double(*it, "shininess");
-        m.color = get_color(*it, "color");
-        materials.push_back(std::move(m));
-    }
-    std::unordered_map<std::string, uint32_t> material_map;
-    for (uint32_t k = 0; k < materials.size(); ++k) {
-        if (material_map.count(materials[k].name) > 0)
-            throw ReadError{"duplicate material name \"" + materials[k].name + "\""};
-        material_map[materials[k].name] = k;
-    }
-
-    // spheres (optional), :583-594
-    struct Sphere { uint32_t mat; Vec3 c; double r; };
-    std::vector<Sphere> spheres;
-    if (has(j, "spheres")) {
-        for (const Value* it : j.find("spheres")->children()) {
-            std::string name = get_string(*it, "material");
-            auto found = material_map.find(name);
-            if (found == material_map.end())
-                throw ReadError{"sphere references undefined material \"" + name + "\""};
-            Sphere s;
-            s.mat = found->second;
-            s.c = get_vector3(*it, "center");
-            s.r = get_positive_double(*it, "radius");
-            spheres.push_back(s);
-        }
-    }
-
-    // triangles (optional), :596-615
-    struct Tri { uint32_t mat; Vec3 a, b, c; };
-    std::vector<Tri> tris;
-    if (has(j, "triangles")) {
-        for (const Value* it : j.find("triangles")->children()) {
-            std::string name = get_string(*it, "material");
-            Tri t;
-            t.a = get_vector3(*it, "a");
-            t.b = get_vector3(*it, "b");
-            t.c = get_vector3(*it, "c");
-            if (same(t.a, t.b) || same(t.a, t.c) || same(t.b, t.c))
-                throw ReadError{"triangle is degenerate due to duplicated vertices"};
-            auto found = material_map.find(name);
-            if (found == material_map.end())
-                throw ReadError{"triangle references undefined material \"" + name + "\""};
-            t.mat = found->second;
-            tris.push_back(t);
-        }
-    }
-
-    // ---- conversion (gfxraytrace.hpp:645-721, :727-808, :881-889) ----
+// One pass over the document in the reference's order of checks (rayson.hpp:380-618); values
+// go straight into the FP32 planes of `out` (the double -> float casts of
+// gfxraytrace.hpp:727-808), objects as spheres first, then triangles (:701-714).
+void build(const Value& document, mrt_loaded_scene& out) {
+    if (!document.is_object()) Fields::reject("rayson must be comprised of one JSON object");   // :382-384
+    const Fields scene(document);
     mrt_scene& s = out.view;
     mrt_scene_info& info = out.info;
 
-    const double vm = std::sqrt(view.x * view.x + view.y * view.y + view.z * view.z);
-    const double w[3] = {-(view.x / vm), -(view.y / vm), -(view.z / vm)};
-    const double cx[3] = {up.y * w[2] - up.z * w[1], up.z * w[0] - up.x * w[2], up.x * w[1] - up.y * w[0]};
-    const double cm = std::sqrt(cx[0] * cx[0] + cx[1] * cx[1] + cx[2] * cx[2]);
-    const double u[3] = {cx[0] / cm, cx[1] / cm, cx[2] / cm};
+    // camera (:489-491) and viewport (:493-498)
+    const Vec3 eye = scene.vec3("camera_eye");
+    const Vec3 up = scene.vec3("camera_up");
+    const Vec3 view = scene.vec3("camera_view");
+    s.xres = scene.count("x_resolution");
+    s.yres = scene.count("y_resolution");
+    info.left = scene.real("viewport_left", Range::Negative);
+    info.top = scene.real("viewport_top", Range::Positive);
+    info.right = scene.real("viewport_right", Range::Positive);
+    info.bottom = scene.real("viewport_bottom", Range::Negative);
+
+    // projection: exactly one of the two keys (:500-521)
+    {
+        const bool ortho = scene.present("ortho_projection"), persp = scene.present("persp_focal_length");
+        if (ortho && persp) Fields::reject("cannot have both ortho_projection and persp_focal_length");
+        if (!ortho && !persp) Fields::reject("must have ortho_projection or persp_focal_length");
+        if (ortho) {
+            if (!scene.flag("ortho_projection")) Fields::reject("ortho_projection, if present, must be true");
+            s.projection = MRT_PROJ_ORTHO;
+            info.focal = 0.0;
+        } else {
+            s.projection = MRT_PROJ_PERSP;
+            info.focal = scene.real("persp_focal_length", Range::Positive);
+        }
+    }
+
+    // shader: flat_shader wins when both are present (:523-540)
+    Vec3 ambient;
+    if (scene.present("flat_shader")) {
+        if (!scene.flag("flat_shader")) Fields::reject("flat_shader, if present, must be true");
+        s.shader = MRT_SHADER_FLAT;
+    } else if (const Value* phong_obj = scene.child("phong_shader")) {
+        const Fields phong(*phong_obj);
+        s.shader = MRT_SHADER_PHONG;
+        info.ka = phong.real("ambient_coeff", Range::NonNegative);
+        info.kd = phong.real("diffuse_coeff", Range::NonNegative);
+        info.ks = phong.real("specular_coeff", Range::NonNegative);
+        ambient = phong.color("ambient_color");
+    } else {
+        Fields::reject("must have flat_shader or phong_shader");
+    }
+    const Vec3 background = scene.color("background");                               // :542
+
+    // point lights, optional (:550-560)
+    if (const Value* list = scene.child("point_lights")) {
+        if (!list->is_array()) Fields::reject("expected point_lights to be an array");
+        for (const Value* item : list->children()) {
+            const Fields light(*item);
+            const Vec3 at = light.vec3("location");
+            append(out.light, 0, at);
+            append(out.light, 3, light.color("color"));
+            out.light_intensity.push_back(light.real("intensity", Range::Positive));
+            for (double c : {at.x, at.y, at.z}) out.light_pos.push_back(c);
+        }
+    }
+
+    // materials, required; names must be unique (:562-581)
+    if (!scene.present("materials")) Fields::reject("no materials list");
+    for (const Value* item : elements(scene, "materials")) {
+        const Fields material(*item);
+        out.material_names.push_back(material.text("name"));
+        out.mat[3].push_back(static_cast<float>(material.real("shininess", Range::Positive)));
+        append(out.mat, 0, material.color("color"));
+    }
+    std::unordered_map<std::string, uint32_t> index_of;
+    for (uint32_t k = 0; k < out.material_names.size(); ++k)
+        if (!index_of.emplace(out.material_names[k], k).second)
+            Fields::reject("duplicate material name \"" + out.material_names[k] + "\"");
+    const auto material_index = [&](const std::string& name, const char* who) {
+        const auto found = index_of.find(name);
+        if (found == index_of.end()) Fields::reject(std::string(who) + " references undefined material \"" + name + "\"");
+        return found->second;
+    };
+
+    // spheres, optional: the material is resolved before the geometry is read (:583-594)
+    for (const Value* item : elements(scene, "spheres")) {
+        const Fields sphere(*item);
+        out.sph_mat.push_back(material_index(sphere.text("material"), "sphere"));
+        append(out.sph, 0, sphere.vec3("center"));
+        out.sph[3].push_back(static_cast<float>(sphere.real("radius", Range::Positive)));
+    }
+
+    // triangles, optional: vertices are read and compared (in double) before the material is
+    // resolved (:596-615)
+    for (const Value* item : elements(scene, "triangles")) {
+        const Fields triangle(*item);
+        const std::string name = triangle.text("material");
+        const Vec3 v[3] = {triangle.vec3("a"), triangle.vec3("b"), triangle.vec3("c")};
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 3; ++q)
+                if (v[p].x == v[q].x && v[p].y == v[q].y && v[p].z == v[q].z)
+                    Fields::reject("triangle is degenerate due to duplicated vertices");
+        out.tri_mat.push_back(material_index(name, "triangle"));
+        for (int p = 0; p < 3; ++p) append(out.tri, 3 * p, v[p]);
+    }
+
+    // Camera basis in double, cast to float only at the end (gfxraytrace.hpp:881-889, :727-734):
+    // w = -view / |view|, u = (up x w) / |up x w|, v = w x u.
+    const double vlen = std::sqrt(view.x * view.x + view.y * view.y + view.z * view.z);
+    const double w[3] = {-(view.x / vlen), -(view.y / vlen), -(view.z / vlen)};
+    const double uw[3] = {up.y * w[2] - up.z * w[1], up.z * w[0] - up.x * w[2], up.x * w[1] - up.y * w[0]};
+    const double ulen = std::sqrt(uw[0] * uw[0] + uw[1] * uw[1] + uw[2] * uw[2]);
+    const double u[3] = {uw[0] / ulen, uw[1] / ulen, uw[2] / ulen};
     const double v[3] = {w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0]};
     const double e[3] = {eye.x, eye.y, eye.z};
     for (int k = 0; k < 3; ++k) {
         info.eye[k] = e[k]; info.u[k] = u[k]; info.v[k] = v[k]; info.w[k] = w[k];
-        s.eye[k] = static_cast<float>(e[k]);
-        s.u[k] = static_cast<float>(u[k]);
-        s.v[k] = static_cast<float>(v[k]);
-        s.w[k] = static_cast<float>(w[k]);
     }
-    s.xres = xres; s.yres = yres;
-    info.left = left; info.top = top; info.right = right; info.bottom = bottom;
-    s.left = static_cast<float>(left); s.right = static_cast<float>(right);
-    s.top = static_cast<float>(top); s.bottom = static_cast<float>(bottom);
-    s.projection = projection;
-    info.focal = focal;
-    s.focal = static_cast<float>(focal);
-    s.shader = shader;
-    info.ka = ka; info.kd = kd; info.ks = ks;
-    s.ka = static_cast<float>(ka); s.kd = static_cast<float>(kd); s.ks = static_cast<float>(ks);
-    s.ambient[0] = static_cast<float>(amb.x); s.ambient[1] = static_cast<float>(amb.y); s.ambient[2] = static_cast<float>(amb.z);
-    s.background[0] = static_cast<float>(background.x);
-    s.background[1] = static_cast<float>(background.y);
-    s.background[2] = static_cast<float>(background.z);
+    store3(s.eye, e); store3(s.u, u); store3(s.v, v); store3(s.w, w);
+    s.left = static_cast<float>(info.left);
+    s.right = static_cast<float>(info.right);
+    s.top = static_cast<float>(info.top);
+    s.bottom = static_cast<float>(info.bottom);
+    s.focal = static_cast<float>(info.focal);
+    s.ka = static_cast<float>(info.ka);
+    s.kd = static_cast<float>(info.kd);
+    s.ks = static_cast<float>(info.ks);
+    const double amb[3] = {ambient.x, ambient.y, ambient.z}, bg[3] = {background.x, background.y, background.z};
+    store3(s.ambient, amb);
+    store3(s.background, bg);
 
-    for (const auto& m : materials) {
-        out.mat[0].push_back(static_cast<float>(m.color.x));
-        out.mat[1].push_back(static_cast<float>(m.color.y));
-        out.mat[2].push_back(static_cast<float>(m.color.z));
-        out.mat[3].push_back(static_cast<float>(m.shininess));
-        out.material_names.push_back(m.name);
-    }
-    for (const auto& sp : spheres) {
-        out.sph[0].push_back(static_cast<float>(sp.c.x));
-        out.sph[1].push_back(static_cast<float>(sp.c.y));
-        out.sph[2].push_back(static_cast<float>(sp.c.z));
-        out.sph[3].push_back(static_cast<float>(sp.r));
-        out.sph_mat.push_back(sp.mat);
-    }
-    for (const auto& t : tris) {
-        const double vals[9] = {t.a.x, t.a.y, t.a.z, t.b.x, t.b.y, t.b.z, t.c.x, t.c.y, t.c.z};
-        for (int k = 0; k < 9; ++k) out.tri[k].push_back(static_cast<float>(vals[k]));
-        out.tri_mat.push_back(t.mat);
-    }
-    for (const auto& l : lights) {
-        out.light[0].push_back(static_cast<float>(l.loc.x));
-        out.light[1].push_back(static_cast<float>(l.loc.y));
-        out.light[2].push_back(static_cast<float>(l.loc.z));
-        out.light[3].push_back(static_cast<float>(l.color.x));
-        out.light[4].push_back(static_cast<float>(l.color.y));
-        out.light[5].push_back(static_cast<float>(l.color.z));
-        out.light_pos.push_back(l.loc.x); out.light_pos.push_back(l.loc.y); out.light_pos.push_back(l.loc.z);
-        out.light_intensity.push_back(l.intensity);
-    }
-
-    s.n_spheres = static_cast<uint32_t>(spheres.size());
+    // the view the C ABI hands out points into the planes above
+    s.n_spheres = static_cast<uint32_t>(out.sph_mat.size());
+    s.n_tris = static_cast<uint32_t>(out.tri_mat.size());
+    s.n_materials = static_cast<uint32_t>(out.material_names.size());
+    s.n_lights = static_cast<uint32_t>(out.light_intensity.size());
     for (int k = 0; k < 4; ++k) s.sph[k] = out.sph[k].data();
-    s.sph_mat = out.sph_mat.data();
-    s.n_tris = static_cast<uint32_t>(tris.size());
     for (int k = 0; k < 9; ++k) s.tri[k] = out.tri[k].data();
-    s.tri_mat = out.tri_mat.data();
-    s.n_materials = static_cast<uint32_t>(materials.size());
     for (int k = 0; k < 4; ++k) s.mat[k] = out.mat[k].data();
-    s.n_lights = static_cast<uint32_t>(lights.size());
     for (int k = 0; k < 6; ++k) s.light[k] = out.light[k].data();
+    s.sph_mat = out.sph_mat.data();
+    s.tri_mat = out.tri_mat.data();
     info.n_lights = s.n_lights;
     info.light_pos = out.light_pos.data();
     info.light_intensity = out.light_intensity.data();
@@ -342,7 +309,7 @@ int load_text(const char* text, size_t len, const std::string& path_for_msg, mrt
     auto* ls = new mrt_loaded_scene();
     try {
         build(root, *ls);
-    } catch (const ReadError& e) {
+    } catch (const Rejected& e) {
         delete ls;
         put_err(err, err_cap, e.message);
         return MRT_ERR_PARSE;
