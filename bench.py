@@ -223,6 +223,7 @@ def secondary_workloads(env, mkscene):
         rays = st.xres * st.yres
         n_prims = st.n_spheres + st.n_tris
         e = {"xres": st.xres, "yres": st.yres, "n_gpus": env.world, "primitives": n_prims,
+             "frames_in_flight": job.in_flight,
              "ms_per_frame": elapsed / steps * 1e3, "mrays_per_s": rays * steps / elapsed * 1e-6,
              "prim_tests_per_s": rays * n_prims * steps / elapsed,
              "rank0_trace_kernel_ms": tr, "rank0_shade_kernel_ms": sh,
@@ -248,7 +249,7 @@ def secondary_workloads(env, mkscene):
             solo = Env()
             solo.__dict__.update(env.__dict__)
             solo.world, solo.rank, solo.use_dist = 1, 0, False
-            job = Job(solo, scene)
+            job = Job(solo, scene, in_flight=FRAMES_IN_FLIGHT)
             elapsed = job.timed(steps, 1)
             job.close()
             res[name]["one_gpu_ms_per_frame"] = elapsed / steps * 1e3
@@ -258,14 +259,14 @@ def secondary_workloads(env, mkscene):
 
     # The 16384 x 16384 triangle soup, one frame split over all ranks (strong scaling).
     soup16k = mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy()
-    job = Job(env, soup16k)
+    job = Job(env, soup16k, in_flight=FRAMES_IN_FLIGHT)
     # (with N ranks the last frame's gather is not hidden behind a next frame: more steps share it)
     frame_stats(job, "soup16k_16384x16384", steps=3 if env.world == 1 else 10, warmup=1, extra={"scaling": "strong"})
     job.close()
     one_gpu_reference(soup16k, "soup16k_16384x16384", steps=3)
     # teatime at 7680 x 4320, split over all ranks.
     tea8k = mrt.LoadedScene(text=mkscene.teatime(7680, 4320)).copy()
-    job = Job(env, tea8k)
+    job = Job(env, tea8k, in_flight=FRAMES_IN_FLIGHT)
     frame_stats(job, "teatime_8k_7680x4320", steps=5 if env.world == 1 else 20, warmup=2, extra={"scaling": "strong"})
     job.close()
     one_gpu_reference(tea8k, "teatime_8k_7680x4320", steps=5)

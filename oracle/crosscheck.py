@@ -13,7 +13,7 @@ holds it to the recorded counts.
 The reference ships nothing executable or recorded for this path, so this narrows what
 "parity unpinned" leaves open; it does not close it.
 
-Run (about ten minutes on 8 cores):  python oracle/crosscheck.py
+Run (about half an hour on 8 cores):  python oracle/crosscheck.py [case ...]
 """
 import json
 import sys
@@ -91,11 +91,17 @@ def cases():
     yield "soup_1024x1024_rows", soup, [(y, y + 1) for y in (3, 130, 257, 384, 511, 640, 770, 900, 1020)]
     soup_o = soup_scene(1024, 1024, "ortho")
     yield "soup_ortho_1024x1024_rows", soup_o, [(y, y + 1) for y in (3, 130, 257, 384, 511, 640, 770, 900, 1020)]
+    # an eighth of the benchmark frame: ten rows out of every eighty, top to bottom
+    yield "teatime_3840x2160_row_blocks", t4k, [(y, y + 10) for y in range(0, 2160, 80)]
 
 
 if __name__ == "__main__":
-    res = {}
+    # with arguments: only the named cases, merged into the existing record
+    only = set(sys.argv[1:])
+    res = json.loads(OUT.read_text()) if (only and OUT.exists()) else {}
     for name, sc, rows in cases():
+        if only and name not in only:
+            continue
         t0 = time.time()
         r = compare(sc, rows)
         r["rows"] = rows if len(rows) > 1 else [list(rows[0])]
