@@ -299,7 +299,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     if (ctx->flags & (MRT_IFLAG_BLOCK_REJECT | MRT_IFLAG_SCREEN_CULL | MRT_FLAG_FULL_TEST)) wide = false;
     const uint32_t block_x = wide ? mrt::TraceWide::block_x : mrt::TraceNarrow::block_x;
     const uint32_t block_y = wide ? mrt::TraceWide::block_y : mrt::TraceNarrow::block_y;
-    const uint32_t tile_x = block_x / mrt::kBlockWavesX, tile_y = block_y / mrt::kBlockWavesY;
+    const uint32_t tile_x = block_x / mrt::kBlockWavesX;
     const uint32_t pitch = round_up(p.xres, block_x);
     const uint32_t prow = round_up(p.local_rows, block_y);
     const size_t plane_elems = (size_t)pitch * prow;
