@@ -359,7 +359,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         d_id = ctx->d_id;
     }
     // The planes are shared by all frames of this ctx: a frame on another stream waits for the last one.
-    if (planes.own && ctx->frame_pending && stream != ctx->last_stream)
+    if (ctx->frame_pending && stream != ctx->last_stream)
         HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->frame_done, 0));
     // The per-view records are built on the ctx's own stream.
     if (ctx->records_pending && stream != ctx->stream)
@@ -483,11 +483,11 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     ctx->last_kernel = kernel;
     ctx->last_slices = p.prim_slices;
     ctx->last_pitch = pitch;
-    if (planes.own) {
-        HIP_TRY(ctx, hipEventRecord(ctx->frame_done, stream));
-        ctx->last_stream = stream;
-        ctx->frame_pending = true;
-    }
+    // Every frame, whatever planes it worked in, reads the per-view records: mrt_set_camera orders
+    // its rebuild behind this event.
+    HIP_TRY(ctx, hipEventRecord(ctx->frame_done, stream));
+    ctx->last_stream = stream;
+    ctx->frame_pending = true;
     return MRT_OK;
 }
 
