@@ -14,8 +14,8 @@ scaling: fixed work per GPU), and every step gathers all bands to rank 0 over
 RCCL; the gather of frame k runs on RCCL's stream while frame k+1 renders (two
 buffer sets per frame in flight).  The headline keeps FRAMES_IN_FLIGHT = 2
 frames enqueued side by side, each on an mrt_ctx and a stream of its own, in
-rotation (a 4K frame alone leaves SIMDs idle while its last waves drain and the
-next frame's first ones start); the same K steps with one frame at a time are
+rotation -- the library's mrt_sequence_* entry points (a 4K frame alone leaves
+SIMDs idle while its last waves drain and the next frame's first ones start); the same K steps with one frame at a time are
 the one_frame_in_flight_* keys.
 
 Rank 0 prints ONE JSON line.  `value` is the throughput of the library's default path
@@ -120,19 +120,22 @@ class Job:
 
     def __init__(self, env, scene, flags=0, in_flight=1):
         """flags: MRT_FLAG_* of a brute-force context, or the name of an mrt_accel method.
-        in_flight: frames enqueued side by side, each on a context and a stream of its own (a
-        context's working planes serve one frame at a time), handed out in rotation: the GPU then
-        starts a frame while the last waves of the one before drain."""
+        in_flight > 1: the frames go through an mrt_sequence, which keeps that many enqueued side
+        by side, each in a slot with a context and a stream of its own, handed out in rotation: the
+        GPU then starts a frame while the last waves of the one before drain."""
         import torch
         self.env, self.scene = env, scene
         st = scene.struct
         self.st = st
         self.in_flight = in_flight
-        self.ctxs = [env.mrt.renderer(device=env.dev_index, kind=flags) for _ in range(in_flight)]
-        for c in self.ctxs:
-            c.set_scene(scene)
-        self.ctx = self.ctxs[0]
-        self.streams = [env.stream] if in_flight == 1 else [torch.cuda.Stream(env.dev) for _ in range(in_flight)]
+        # one frame at a time (and the kernel timings of every job): a plain context on torch's stream
+        self.ctx = env.mrt.renderer(device=env.dev_index, kind=flags)
+        self.ctx.set_scene(scene)
+        self.seq = None
+        if in_flight > 1:
+            self.seq = env.mrt.Sequence(device=env.dev_index, flags=int(flags), in_flight=in_flight)
+            self.seq.set_scene(scene)
+        self.slot_streams = [env.stream] if in_flight == 1 else [None] * in_flight
         mrt, world = env.mrt, env.world
         self.rows = mrt.band_rows(st.yres, BAND_ROWS, env.rank, world)
         nbytes = max(mrt.band_rows(st.yres, BAND_ROWS, r, world) for r in range(world)) * st.xres * 4
@@ -146,13 +149,21 @@ class Job:
     def step(self, k):
         import torch
         env, b, f = self.env, k % self.n_sets, k % self.in_flight
-        with torch.cuda.stream(self.streams[f]):
-            if self.works[b] is not None:
-                self.works[b].wait()     # stream-level wait: the last gather out of buffer b is done
-                self.works[b] = None
-            self.ctxs[f].render_bands_device(BAND_ROWS, env.rank, env.world, self.local[b].data_ptr(),
-                                             self.local[b].numel(), stream=self.streams[f].cuda_stream)
-            if env.use_dist:
+        if self.works[b] is not None:
+            # stream-level wait on the slot's stream: the last gather out of buffer b is done
+            # (a buffer comes round again only after its slot's stream is known)
+            with torch.cuda.stream(self.slot_streams[f]):
+                self.works[b].wait()
+            self.works[b] = None
+        if self.seq is None:
+            self.ctx.render_bands_device(BAND_ROWS, env.rank, env.world, self.local[b].data_ptr(),
+                                         self.local[b].numel(), stream=env.stream.cuda_stream)
+        else:
+            ptr = self.seq.submit(BAND_ROWS, env.rank, env.world, self.local[b].data_ptr(), self.local[b].numel())
+            if self.slot_streams[f] is None:
+                self.slot_streams[f] = torch.cuda.ExternalStream(ptr, device=env.dev)
+        if env.use_dist:
+            with torch.cuda.stream(self.slot_streams[f]):
                 if env.rehearsal:
                     env.dist.gather(self.local[b].cpu(), self.gathered[b], dst=0)
                 else:
@@ -206,8 +217,9 @@ class Job:
         return sum(tr) / len(tr), sum(sh) / len(sh)
 
     def close(self):
-        for c in self.ctxs:
-            c.close()
+        self.ctx.close()
+        if self.seq is not None:
+            self.seq.close()
         self.local = self.gathered = None
 
 

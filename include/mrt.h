@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 4
+#define MRT_ABI_VERSION 5
 
 typedef enum mrt_status {
     MRT_OK = 0,
@@ -186,7 +186,9 @@ typedef struct mrt_camera {
 
 /* Replace the view of the scene last given to mrt_set_scene: geometry,
  * materials, lights and shader stay on the GPU, only the per-view records
- * are rebuilt.  Waits for frames still in flight on this device.  The
+ * are rebuilt, by kernels on the ctx's own stream: the call does not wait for
+ * the GPU, it is ordered behind the frames already enqueued and the next
+ * frame, on whatever stream, behind it.  The
  * reference has no equivalent: it re-creates context, program and buffers in
  * every stage call (CLHelpers.hpp:79,119,155,196,242,281). */
 int mrt_set_camera(mrt_ctx *ctx, const mrt_camera *camera);
@@ -310,6 +312,48 @@ int mrt_multi_set_camera(mrt_multi *m, const mrt_camera *camera);
 /* mrt_render_rgba8 over all ranks: same bytes as one GPU renders.  host_out is
  * best page-locked (mrt_host_alloc): the band copies then run asynchronously. */
 int mrt_multi_render_rgba8(mrt_multi *m, uint8_t *host_out, mrt_multi_stats *stats /* may be NULL */);
+
+/* ------------------------------------------------------------------------
+ * Many frames of one scene on one GPU, several of them in flight: a turntable,
+ * an animation, a stream of views to serve.  A frame alone leaves part of the
+ * GPU idle while its last waves drain, its shading launch runs and the next
+ * frame's first waves start (about 9 % of a 3840x2160 frame); a sequence keeps
+ * in_flight frames enqueued side by side, each in a slot with working buffers,
+ * per-view records and a stream of its own, so that the next frame fills those
+ * gaps.  Frame k goes to slot k mod in_flight and runs behind frame
+ * k - in_flight.  The multi-frame caller the reference cannot serve: it sets up
+ * context, program and buffers anew in every stage call
+ * (CLHelpers.hpp:79,119,155,196,242,281).
+ * ---------------------------------------------------------------------- */
+typedef struct mrt_sequence_config {
+    int32_t device;       /* HIP ordinal, -1 = the current device             */
+    uint32_t flags;       /* MRT_FLAG_* of the slots' brute-force contexts     */
+    uint32_t in_flight;   /* slots, 1 .. 4; 0 = 2                              */
+} mrt_sequence_config;
+
+typedef struct mrt_sequence mrt_sequence;
+
+int mrt_sequence_create(const mrt_sequence_config *cfg, mrt_sequence **out);
+void mrt_sequence_destroy(mrt_sequence *q);
+/* Text of the last error on q (of the last failed mrt_sequence_create when q is NULL). */
+const char *mrt_sequence_last_error(const mrt_sequence *q);
+uint32_t mrt_sequence_in_flight(const mrt_sequence *q);
+/* mrt_set_scene on every slot; waits for the frames in flight. */
+int mrt_sequence_set_scene(mrt_sequence *q, const mrt_scene *scene);
+/* Enqueue the next frame and return at once: `view` (NULL = the view of the
+ * frame before, or of the scene as given) and this rank's interleaved bands
+ * into dev_out, exactly as mrt_render_bands_device writes them.  The frame runs
+ * on its slot's stream; *frame_stream (may be NULL) receives that hipStream_t,
+ * so that the caller can chain what consumes dev_out (a gather, a copy) behind
+ * the frame, or make a stream of its own wait for it.  dev_out belongs to the
+ * frame until that stream has passed it (or mrt_sequence_wait has returned);
+ * work the caller chained on the slot's stream is what frame k + in_flight
+ * runs behind. */
+int mrt_sequence_submit(mrt_sequence *q, const mrt_camera *view, uint32_t band_rows, uint32_t rank,
+                        uint32_t world, void *dev_out, size_t dev_out_bytes, void **frame_stream);
+/* Returns when every frame submitted so far (and whatever the caller chained on
+ * the slots' streams) has completed. */
+int mrt_sequence_wait(mrt_sequence *q);
 
 /* ------------------------------------------------------------------------
  * Screen-space acceleration: the same pixels without testing every pair.

@@ -26,7 +26,7 @@ RESERVED_FLAG_BITS = (1 << 2) | (1 << 4)          # mrt_create refuses them
 KERNEL_TRACE, KERNEL_TRACE_BLOCK, KERNEL_CULL, KERNEL_FULL, KERNEL_GRID, KERNEL_TRACE_WIDE = 0, 1, 2, 3, 4, 5    # mrt_stats.kernel
 ACCEL_GRID, ACCEL_TILE_CULL, ACCEL_BLOCK_REJECT = 0, 1, 2                                 # mrt_accel_config.method
 ACCEL_METHODS = {"grid": ACCEL_GRID, "cull": ACCEL_TILE_CULL, "block": ACCEL_BLOCK_REJECT}
-ABI_VERSION = 4
+ABI_VERSION = 5
 PROJ_ORTHO, PROJ_PERSP = 0, 1
 SHADER_FLAT, SHADER_PHONG = 0, 1
 
@@ -43,6 +43,8 @@ EXPORTED_SYMBOLS = [
     "mrt_multi_note", "mrt_multi_set_scene", "mrt_multi_set_camera", "mrt_multi_render_rgba8",
     "mrt_accel_create", "mrt_accel_destroy", "mrt_accel_last_error", "mrt_accel_method", "mrt_accel_set_scene",
     "mrt_accel_set_camera", "mrt_accel_render_rgba8", "mrt_accel_render_debug", "mrt_accel_render_bands_device",
+    "mrt_sequence_create", "mrt_sequence_destroy", "mrt_sequence_last_error", "mrt_sequence_in_flight",
+    "mrt_sequence_set_scene", "mrt_sequence_submit", "mrt_sequence_wait",
 ]
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST = 0, 1, 2, 3
 NOALLOC_MAX_KEYS = 8 * 1024 * 1024
@@ -113,6 +115,10 @@ class AccelStats(C.Structure):
         d = self.frame.as_dict()
         d.update(build_ms=self.build_ms, cells=self.cells, refs=self.refs)
         return d
+
+
+class SequenceConfigStruct(C.Structure):
+    _fields_ = [("device", C.c_int32), ("flags", C.c_uint32), ("in_flight", C.c_uint32)]
 
 
 class MultiConfigStruct(C.Structure):
@@ -231,6 +237,17 @@ def lib():
     L.mrt_multi_set_scene.argtypes = [vp, C.POINTER(SceneStruct)]
     L.mrt_multi_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
     L.mrt_multi_render_rgba8.argtypes = [vp, vp, C.POINTER(MultiStats)]
+    L.mrt_sequence_create.argtypes = [C.POINTER(SequenceConfigStruct), C.POINTER(vp)]
+    L.mrt_sequence_destroy.argtypes = [vp]
+    L.mrt_sequence_destroy.restype = None
+    L.mrt_sequence_last_error.argtypes = [vp]
+    L.mrt_sequence_last_error.restype = C.c_char_p
+    L.mrt_sequence_in_flight.argtypes = [vp]
+    L.mrt_sequence_in_flight.restype = C.c_uint32
+    L.mrt_sequence_set_scene.argtypes = [vp, C.POINTER(SceneStruct)]
+    L.mrt_sequence_submit.argtypes = [vp, C.POINTER(CameraStruct), C.c_uint32, C.c_uint32, C.c_uint32, vp,
+                                      C.c_size_t, C.POINTER(vp)]
+    L.mrt_sequence_wait.argtypes = [vp]
     L.mrt_accel_create.argtypes = [C.POINTER(AccelConfigStruct), C.POINTER(vp)]
     L.mrt_accel_destroy.argtypes = [vp]
     L.mrt_accel_destroy.restype = None
@@ -607,6 +624,56 @@ class MultiContext:
     def close(self):
         if self._h:
             lib().mrt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Sequence:
+    """mrt_sequence: many frames of one scene on one GPU, in_flight of them enqueued side by side."""
+
+    def __init__(self, device=-1, flags=FLAG_NONE, in_flight=0):
+        L = lib()
+        self._h = C.c_void_p()
+        cfg = SequenceConfigStruct(device, flags, in_flight)
+        rc = L.mrt_sequence_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise MrtError(rc, L.mrt_sequence_last_error(None).decode())
+        self.in_flight = L.mrt_sequence_in_flight(self._h)
+        self.xres = self.yres = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MrtError(rc, lib().mrt_sequence_last_error(self._h).decode())
+
+    def set_scene(self, scene):
+        st = scene.struct
+        self._check(lib().mrt_sequence_set_scene(self._h, C.byref(st)))
+        self.xres, self.yres = st.xres, st.yres
+
+    def submit(self, band_rows_, rank, world, dev_ptr, nbytes, view=None):
+        """Enqueues the next frame (view: a Scene whose camera / viewport to take, None = as the
+        frame before) and returns the hipStream_t it runs on, as an integer."""
+        cam = None
+        if view is not None:
+            cam = _camera_of(view.struct)
+        stream = C.c_void_p()
+        self._check(lib().mrt_sequence_submit(self._h, C.byref(cam) if cam is not None else None, band_rows_, rank,
+                                              world, dev_ptr, nbytes, C.byref(stream)))
+        if view is not None:
+            self.xres, self.yres = view.struct.xres, view.struct.yres
+        return stream.value or 0
+
+    def wait(self):
+        self._check(lib().mrt_sequence_wait(self._h))
+
+    def close(self):
+        if self._h:
+            lib().mrt_sequence_destroy(self._h)
             self._h = None
 
     def __del__(self):

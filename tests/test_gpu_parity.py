@@ -611,6 +611,85 @@ def test_set_camera_equals_fresh_scene(mrt, oracle):
         fresh.close()
 
 
+def _scene_with_view(mrt, base, view):
+    """`base` (geometry, materials, lights, shader) seen through the camera and viewport of `view`."""
+    st, b = view.struct, base.struct
+    return mrt.Scene(eye=list(st.eye), u=list(st.u), v=list(st.v), w=list(st.w), xres=st.xres, yres=st.yres,
+                     left=st.left, right=st.right, top=st.top, bottom=st.bottom, projection=st.projection,
+                     focal=st.focal, shader=b.shader, ka=b.ka, kd=b.kd, ks=b.ks, ambient=list(b.ambient),
+                     background=list(b.background), sph=base.sph, sph_mat=base.sph_mat, tri=base.tri,
+                     tri_mat=base.tri_mat, mat=base.mat, light=base.light)
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_sequence_of_views_equals_fresh_contexts(mrt, in_flight):
+    """mrt_sequence: views submitted back to back, in_flight of them enqueued side by side, each
+    into its own buffer; every frame equals what a fresh context renders for its view, also when
+    the view stays (NULL) and when the resolution changes in mid-sequence."""
+    import torch
+    rng = np.random.default_rng(77)
+    base = _random_scene(mrt, rng, mrt.PROJ_PERSP, 320, 200, 900, 40)
+    b = base.struct
+    eye0, w0, v0 = np.array(list(b.eye)), np.array(list(b.w)), np.array(list(b.v))
+
+    def nearby_view(k):
+        """The camera of `base` moved and turned a little, viewport and resolution varied."""
+        u, v, w = scene_py.camera_basis(list(-w0 + rng.normal(scale=0.08, size=3)), list(v0 + rng.normal(scale=0.1, size=3)))
+        xres, yres = (320, 200) if k < 5 else (256, 160)
+        return mrt.Scene(eye=eye0 + rng.normal(scale=0.3, size=3), u=u, v=v, w=w, xres=xres, yres=yres,
+                         left=-1.2 + 0.05 * k, right=0.9, top=0.7 + 0.03 * k, bottom=-1.1,
+                         projection=mrt.PROJ_PERSP, focal=float(b.focal) * (1 + 0.05 * k), shader=b.shader, ka=b.ka,
+                         kd=b.kd, ks=b.ks, ambient=list(b.ambient), background=list(b.background), sph=base.sph,
+                         sph_mat=base.sph_mat, tri=base.tri, tri_mat=base.tri_mat, mat=base.mat, light=base.light)
+
+    views = [None]                                                   # first frame: the scene's own view
+    for k in range(7):
+        views.append(nearby_view(k))
+        if k in (2, 3, 6):
+            views.append(None)                                       # the same view once more
+    seq = mrt.Sequence(device=0, in_flight=in_flight)
+    fresh = mrt.Context(device=0)
+    try:
+        assert seq.in_flight == in_flight
+        with pytest.raises(mrt.MrtError) as e:
+            seq.submit(200, 0, 1, 0, 0)
+        assert e.value.code == -4
+        seq.set_scene(base)
+        bufs = [torch.zeros(320 * 200 * 4, dtype=torch.uint8, device="cuda:0") for _ in views]
+        torch.cuda.synchronize()
+        streams = set()
+        current = base
+        for view, buf in zip(views, bufs):
+            current = view if view is not None else current
+            streams.add(seq.submit(current.struct.yres, 0, 1, buf.data_ptr(), buf.numel(), view=view))
+        assert len(streams) == in_flight and 0 not in streams
+        seq.wait()
+        current = base
+        for k, (view, buf) in enumerate(zip(views, bufs)):
+            current = view if view is not None else current
+            fresh.set_scene(current)
+            want, _ = fresh.render()
+            assert len(np.unique(want.reshape(-1, 4), axis=0)) > 20, k     # the view does show the scene
+            st = current.struct
+            got = buf.cpu().numpy()[:st.xres * st.yres * 4].reshape(st.yres, st.xres, 4)
+            assert np.array_equal(got, want), k
+        # a rejected view leaves the sequence where it was
+        bad = nearby_view(0)
+        bad.struct.projection = 7
+        with pytest.raises(mrt.MrtError):
+            seq.submit(200, 0, 1, bufs[0].data_ptr(), bufs[0].numel(), view=bad)
+        st = current.struct
+        seq.submit(st.yres, 0, 1, bufs[0].data_ptr(), bufs[0].numel())
+        seq.wait()
+        assert np.array_equal(bufs[0].cpu().numpy()[:st.xres * st.yres * 4].reshape(st.yres, st.xres, 4), want)
+    finally:
+        seq.close()
+        fresh.close()
+    with pytest.raises(mrt.MrtError) as e:
+        mrt.Sequence(device=0, in_flight=5)
+    assert e.value.code == -5
+
+
 def test_render_is_deterministic(gpu_ctx, mrt):
     ls = mrt.LoadedScene(text=mkscene.teatime(1280, 720)).copy()
     a = gpu_render(gpu_ctx, ls)
