@@ -659,6 +659,13 @@ int mrt_accel_set_camera(mrt_accel* a, const mrt_camera* camera) {
     if (!a) return MRT_ERR_INVALID;
     if (!a->have_scene) return afail(a, MRT_ERR_NO_SCENE, "mrt_accel_set_scene has not succeeded on this handle");
     a->have_scene = false;
+    if (a->method == MRT_ACCEL_GRID && a->frame_pending) {
+        // a grid frame still in flight on a caller's stream reads the per-view records that
+        // mrt_set_camera is about to rebuild on the base context's stream
+        AccelDeviceGuard guard(a->device);
+        AHIP_TRY(a, guard.err);
+        AHIP_TRY(a, hipStreamWaitEvent((hipStream_t)mrt_ctx_stream_(a->base), a->frame_done, 0));
+    }
     int rc = mrt_set_camera(a->base, camera);
     if (rc != MRT_OK) return base_failed(a, rc);
     if (a->method == MRT_ACCEL_GRID) {
