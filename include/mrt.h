@@ -321,7 +321,8 @@ int mrt_multi_render_rgba8(mrt_multi *m, uint8_t *host_out, mrt_multi_stats *sta
  * in_flight frames enqueued side by side, each in a slot with working buffers,
  * per-view records and a stream of its own, so that the next frame fills those
  * gaps.  Frame k goes to slot k mod in_flight and runs behind frame
- * k - in_flight.  The multi-frame caller the reference cannot serve: it sets up
+ * k - in_flight.  One thread at a time per sequence.  The multi-frame caller
+ * the reference cannot serve: it sets up
  * context, program and buffers anew in every stage call
  * (CLHelpers.hpp:79,119,155,196,242,281).
  * ---------------------------------------------------------------------- */
