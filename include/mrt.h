@@ -335,6 +335,10 @@ typedef struct mrt_sequence_config {
 typedef struct mrt_sequence mrt_sequence;
 
 int mrt_sequence_create(const mrt_sequence_config *cfg, mrt_sequence **out);
+/* Waits for the frames in flight, then destroys the slots and their streams:
+ * whatever the caller chained on those streams must be over, and a framework
+ * that remembers streams (an allocator that records an event on the stream a
+ * buffer was last used on when the buffer is freed) must have let go of them. */
 void mrt_sequence_destroy(mrt_sequence *q);
 /* Text of the last error on q (of the last failed mrt_sequence_create when q is NULL). */
 const char *mrt_sequence_last_error(const mrt_sequence *q);
