@@ -404,54 +404,25 @@ def host_frame(env, job, total_rays):
             dl = hs.download_ms
         res[label] = {"ms_per_frame": min(host_ms), "download_ms": dl,
                       "mrays_per_s": total_rays / min(host_ms) * 1e-3}
-    # A stream of frames into page-locked host memory through mrt_sequence: the copy of frame k
-    # runs on a copy stream behind an event on the frame's slot stream, into one of four buffer
-    # pairs, while the slots go on rendering (copies chained on the slot streams themselves would
-    # make the slots render together and copy together).
-    import torch
+    # A stream of frames into page-locked host memory through mrt_sequence_submit_host: the copy of
+    # frame k runs on the sequence's copy stream while its slots go on rendering.
     seq = env.mrt.Sequence(device=env.dev_index, in_flight=FRAMES_IN_FLIGHT)
-    n_buf = 2 * FRAMES_IN_FLIGHT
-    streams, host, dev, copied = {}, None, None, [None] * n_buf
-    copy_stream = torch.cuda.Stream(env.dev)
     try:
         seq.set_scene(job.scene)
-        nbytes = job.st.xres * job.st.yres * 4
-        dev = [torch.empty(nbytes, dtype=torch.uint8, device=env.dev) for _ in range(n_buf)]
-        host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(n_buf)]
-        slot_stream = [None] * FRAMES_IN_FLIGHT
-
-        def frames(n):
-            for k in range(n):
-                b, f = k % n_buf, k % FRAMES_IN_FLIGHT
-                if copied[b] is not None:                  # the frame may not overwrite a buffer still being copied
-                    slot_stream[f].wait_event(copied[b])
-                ptr = seq.submit(job.st.yres, 0, 1, dev[b].data_ptr(), nbytes)
-                if slot_stream[f] is None:
-                    slot_stream[f] = streams.setdefault(ptr, torch.cuda.ExternalStream(ptr, device=env.dev))
-                rendered = torch.cuda.Event()
-                rendered.record(slot_stream[f])
-                copy_stream.wait_event(rendered)
-                with torch.cuda.stream(copy_stream):
-                    host[b].copy_(dev[b], non_blocking=True)
-                    copied[b] = torch.cuda.Event()
-                    copied[b].record(copy_stream)
-            seq.wait()
-            copy_stream.synchronize()
-
-        frames(2 * n_buf)
+        outs = [env.mrt.host_array((job.st.yres, job.st.xres, 4)) for _ in range(2 * FRAMES_IN_FLIGHT)]
+        for k in range(len(outs)):
+            seq.submit_host(outs[k])
+        seq.wait()
         n = 20
         t1 = time.perf_counter()
-        frames(n)
+        for k in range(n):
+            seq.submit_host(outs[k % len(outs)])
+        seq.wait()
         dt = (time.perf_counter() - t1) / n * 1e3
-        same = all(bool((h.numpy().reshape(job.st.yres, job.st.xres, 4) == img).all()) for h in host)
+        same = all(bool((o == img).all()) for o in outs)
         res["pinned_sequence"] = {"ms_per_frame": dt, "mrays_per_s": total_rays / dt * 1e-3, "frames": n,
                                   "frames_in_flight": FRAMES_IN_FLIGHT, "same_bytes_as_one_frame": same}
     finally:
-        # torch's pinned-memory allocator remembers the streams a block was used on and records an
-        # event there when the block is freed: the blocks go before the streams do
-        host = dev = None
-        torch.cuda.synchronize(env.dev)
-        streams.clear()
         seq.close()
     with tempfile.TemporaryDirectory() as d:
         t1 = time.perf_counter()

@@ -356,6 +356,15 @@ int mrt_sequence_set_scene(mrt_sequence *q, const mrt_scene *scene);
  * runs behind. */
 int mrt_sequence_submit(mrt_sequence *q, const mrt_camera *view, uint32_t band_rows, uint32_t rank,
                         uint32_t world, void *dev_out, size_t dev_out_bytes, void **frame_stream);
+/* The same for a caller who wants the frames in host memory: the whole frame
+ * (xres*yres RGBA8 of the view, as mrt_render_rgba8 writes it) is rendered
+ * into a device buffer of the sequence (2 x in_flight of them, in rotation)
+ * and copied to host_out by a copy stream of the sequence's own, behind the
+ * frame and beside the frames that follow: in a stream of frames the copies
+ * cost nothing (1.20 ms per 3840x2160 frame in page-locked memory, against 1.81
+ * for mrt_render_rgba8 frame by frame).  Returns at once; host_out -- best
+ * page-locked (mrt_host_alloc) -- is complete when mrt_sequence_wait returns. */
+int mrt_sequence_submit_host(mrt_sequence *q, const mrt_camera *view, uint8_t *host_out);
 /* Returns when every frame submitted so far (and whatever the caller chained on
  * the slots' streams) has completed. */
 int mrt_sequence_wait(mrt_sequence *q);

@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "mrt_accel_create", "mrt_accel_destroy", "mrt_accel_last_error", "mrt_accel_method", "mrt_accel_set_scene",
     "mrt_accel_set_camera", "mrt_accel_render_rgba8", "mrt_accel_render_debug", "mrt_accel_render_bands_device",
     "mrt_sequence_create", "mrt_sequence_destroy", "mrt_sequence_last_error", "mrt_sequence_in_flight",
-    "mrt_sequence_set_scene", "mrt_sequence_submit", "mrt_sequence_wait",
+    "mrt_sequence_set_scene", "mrt_sequence_submit", "mrt_sequence_submit_host", "mrt_sequence_wait",
 ]
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_HOST = 0, 1, 2, 3
 NOALLOC_MAX_KEYS = 8 * 1024 * 1024
@@ -247,6 +247,7 @@ def lib():
     L.mrt_sequence_set_scene.argtypes = [vp, C.POINTER(SceneStruct)]
     L.mrt_sequence_submit.argtypes = [vp, C.POINTER(CameraStruct), C.c_uint32, C.c_uint32, C.c_uint32, vp,
                                       C.c_size_t, C.POINTER(vp)]
+    L.mrt_sequence_submit_host.argtypes = [vp, C.POINTER(CameraStruct), vp]
     L.mrt_sequence_wait.argtypes = [vp]
     L.mrt_accel_create.argtypes = [C.POINTER(AccelConfigStruct), C.POINTER(vp)]
     L.mrt_accel_destroy.argtypes = [vp]
@@ -667,6 +668,17 @@ class Sequence:
         if view is not None:
             self.xres, self.yres = view.struct.xres, view.struct.yres
         return stream.value or 0
+
+    def submit_host(self, out, view=None):
+        """Enqueues the next frame into `out`, a C-contiguous uint8 array of shape (yres, xres, 4) of the
+        frame's view (best from host_array()); complete after wait()."""
+        cam = _camera_of(view.struct) if view is not None else None
+        xres, yres = (view.struct.xres, view.struct.yres) if view is not None else (self.xres, self.yres)
+        if out.shape != (yres, xres, 4) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of shape (yres, xres, 4)")
+        self._check(lib().mrt_sequence_submit_host(self._h, C.byref(cam) if cam is not None else None,
+                                                   out.ctypes.data))
+        self.xres, self.yres = xres, yres
 
     def wait(self):
         self._check(lib().mrt_sequence_wait(self._h))

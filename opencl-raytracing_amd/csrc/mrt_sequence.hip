@@ -24,6 +24,15 @@ struct Slot {
     uint64_t view_serial = 0;        // which of the sequence's views the slot's records are built for
 };
 
+// A device frame buffer of mrt_sequence_submit_host and the events around its use.
+struct HostLane {
+    uint8_t* dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t rendered = nullptr;   // the frame is in `dev`
+    hipEvent_t copied = nullptr;     // `dev` has been copied out and may be overwritten
+    bool used = false;
+};
+
 struct KeepDevice {
     int prev = -1;
     KeepDevice() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
@@ -40,6 +49,11 @@ struct mrt_sequence {
     mrt_camera view{};               // the view of the last frame submitted (of the scene at first)
     uint64_t view_serial = 0;
     uint64_t next = 0;               // frames submitted so far
+    // mrt_sequence_submit_host: 2 x in_flight device buffers, taken in rotation, and the stream
+    // the copies to the host run on (made on first use)
+    std::vector<HostLane> lanes;
+    hipStream_t copy_stream = nullptr;
+    uint64_t host_next = 0;
 };
 
 namespace {
@@ -63,6 +77,13 @@ void mrt_sequence_destroy(mrt_sequence* q) {
     (void)hipSetDevice(q->device);
     for (Slot& s : q->slots)
         if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (q->copy_stream) (void)hipStreamSynchronize(q->copy_stream);
+    for (HostLane& l : q->lanes) {
+        if (l.dev) (void)hipFree(l.dev);
+        if (l.rendered) (void)hipEventDestroy(l.rendered);
+        if (l.copied) (void)hipEventDestroy(l.copied);
+    }
+    if (q->copy_stream) (void)hipStreamDestroy(q->copy_stream);
     for (Slot& s : q->slots) {
         if (s.ctx) mrt_destroy(s.ctx);
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -112,6 +133,7 @@ int mrt_sequence_wait(mrt_sequence* q) {
     hipError_t e = hipSetDevice(q->device);
     for (Slot& s : q->slots)
         if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+    if (e == hipSuccess && q->copy_stream) e = hipStreamSynchronize(q->copy_stream);
     if (e != hipSuccess) return qfail(q, MRT_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return MRT_OK;
 }
@@ -138,13 +160,10 @@ int mrt_sequence_set_scene(mrt_sequence* q, const mrt_scene* scene) {
     return MRT_OK;
 }
 
-int mrt_sequence_submit(mrt_sequence* q, const mrt_camera* view, uint32_t band_rows, uint32_t rank,
-                        uint32_t world, void* dev_out, size_t dev_out_bytes, void** frame_stream) {
-    if (!q) return MRT_ERR_INVALID;
-    if (frame_stream) *frame_stream = nullptr;
-    if (!q->have_scene) return qfail(q, MRT_ERR_NO_SCENE, "mrt_sequence_set_scene has not succeeded");
+// The slot of the next frame, with `view` (NULL = as before) taken: a new view counts only once
+// a slot has accepted it.
+static int next_slot(mrt_sequence* q, const mrt_camera* view, Slot** out) {
     Slot& s = q->slots[q->next % q->slots.size()];
-    // a new view counts only once a slot has taken it
     const mrt_camera& want = view ? *view : q->view;
     const uint64_t want_serial = q->view_serial + (view ? 1u : 0u);
     if (s.view_serial != want_serial) {
@@ -157,9 +176,68 @@ int mrt_sequence_submit(mrt_sequence* q, const mrt_camera* view, uint32_t band_r
         q->view = *view;
         q->view_serial = want_serial;
     }
-    const int rc = mrt_render_bands_device(s.ctx, band_rows, rank, world, dev_out, dev_out_bytes, s.stream, nullptr);
-    if (rc != MRT_OK) return qfail(q, rc, mrt_last_error(s.ctx));
-    if (frame_stream) *frame_stream = (void*)s.stream;
+    *out = &s;
+    return MRT_OK;
+}
+
+int mrt_sequence_submit(mrt_sequence* q, const mrt_camera* view, uint32_t band_rows, uint32_t rank,
+                        uint32_t world, void* dev_out, size_t dev_out_bytes, void** frame_stream) {
+    if (!q) return MRT_ERR_INVALID;
+    if (frame_stream) *frame_stream = nullptr;
+    if (!q->have_scene) return qfail(q, MRT_ERR_NO_SCENE, "mrt_sequence_set_scene has not succeeded");
+    Slot* s = nullptr;
+    int rc = next_slot(q, view, &s);
+    if (rc != MRT_OK) return rc;
+    rc = mrt_render_bands_device(s->ctx, band_rows, rank, world, dev_out, dev_out_bytes, s->stream, nullptr);
+    if (rc != MRT_OK) return qfail(q, rc, mrt_last_error(s->ctx));
+    if (frame_stream) *frame_stream = (void*)s->stream;
+    ++q->next;
+    return MRT_OK;
+}
+
+int mrt_sequence_submit_host(mrt_sequence* q, const mrt_camera* view, uint8_t* host_out) {
+    if (!q) return MRT_ERR_INVALID;
+    if (!q->have_scene) return qfail(q, MRT_ERR_NO_SCENE, "mrt_sequence_set_scene has not succeeded");
+    if (!host_out) return qfail(q, MRT_ERR_INVALID, "host_out is NULL");
+    KeepDevice keep;
+#define QHIP(expr)                                                                                       \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return qfail(q, MRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+    QHIP(hipSetDevice(q->device));
+    if (!q->copy_stream) {
+        QHIP(hipStreamCreateWithFlags(&q->copy_stream, hipStreamNonBlocking));
+        q->lanes.resize(2 * q->slots.size());
+        for (HostLane& l : q->lanes) {
+            QHIP(hipEventCreateWithFlags(&l.rendered, hipEventDisableTiming));
+            QHIP(hipEventCreateWithFlags(&l.copied, hipEventDisableTiming));
+        }
+    }
+    Slot* s = nullptr;
+    int rc = next_slot(q, view, &s);
+    if (rc != MRT_OK) return rc;
+    const size_t bytes = (size_t)q->view.xres * q->view.yres * 4;
+    HostLane& l = q->lanes[q->host_next % q->lanes.size()];
+    if (bytes > l.cap) {
+        if (l.used) QHIP(hipEventSynchronize(l.copied));       // the copy out of the buffer freed here
+        if (l.dev) { (void)hipFree(l.dev); l.dev = nullptr; }
+        l.cap = 0;
+        l.used = false;
+        QHIP(hipMalloc((void**)&l.dev, bytes));
+        l.cap = bytes;
+    }
+    // the frame may not overwrite a buffer whose last frame is still on its way to the host
+    if (l.used) QHIP(hipStreamWaitEvent(s->stream, l.copied, 0));
+    rc = mrt_render_bands_device(s->ctx, q->view.yres, 0, 1, l.dev, bytes, s->stream, nullptr);
+    if (rc != MRT_OK) return qfail(q, rc, mrt_last_error(s->ctx));
+    QHIP(hipEventRecord(l.rendered, s->stream));
+    QHIP(hipStreamWaitEvent(q->copy_stream, l.rendered, 0));
+    QHIP(hipMemcpyAsync(host_out, l.dev, bytes, hipMemcpyDeviceToHost, q->copy_stream));
+    QHIP(hipEventRecord(l.copied, q->copy_stream));
+#undef QHIP
+    l.used = true;
+    ++q->host_next;
     ++q->next;
     return MRT_OK;
 }

@@ -673,6 +673,23 @@ def test_sequence_of_views_equals_fresh_contexts(mrt, in_flight):
             st = current.struct
             got = buf.cpu().numpy()[:st.xres * st.yres * 4].reshape(st.yres, st.xres, 4)
             assert np.array_equal(got, want), k
+        # the same sequence into host memory (mrt_sequence_submit_host): the library's own device
+        # buffers and copy stream, page-locked and pageable destinations
+        current, outs = base, []
+        seq.set_scene(base)
+        for k, view in enumerate(views):
+            current = view if view is not None else current
+            st = current.struct
+            out = mrt.host_array((st.yres, st.xres, 4)) if k % 3 else np.zeros((st.yres, st.xres, 4), np.uint8)
+            seq.submit_host(out, view=view)
+            outs.append((current, out))
+        seq.wait()
+        for k, (sc_k, out) in enumerate(outs):
+            fresh.set_scene(sc_k)
+            want, _ = fresh.render()
+            assert np.array_equal(out, want), k
+        with pytest.raises(ValueError):
+            seq.submit_host(np.zeros((3, 3, 4), np.uint8))
         # a rejected view leaves the sequence where it was
         bad = nearby_view(0)
         bad.struct.projection = 7
