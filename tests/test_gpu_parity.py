@@ -707,6 +707,36 @@ def test_sequence_of_views_equals_fresh_contexts(mrt, in_flight):
     assert e.value.code == -5
 
 
+def test_slice_and_layer_count_invariance(mrt, monkeypatch):
+    """The triangle list cut into any number of slices (trace_kernel, both lane shapes) or layers
+    (full_trace_kernel) gives the same winners, t and bytes as one piece: the pieces meet in the
+    key plane, whose minimum does not depend on how the list was cut (MRT_FORCE_SLICES is the
+    library's tuning override of the automatic choice)."""
+    scenes = [mrt.LoadedScene(text=mkscene.teatime(640, 360)).copy(),
+              mrt.LoadedScene(text=mkscene.soup(333, 222, n_tris=1500, n_spheres=700, seed=3, projection="ortho")).copy()]
+    for flags in (mrt.FLAG_TRACE_NARROW, mrt.FLAG_TRACE_WIDE, mrt.FLAG_FULL_TEST):
+        ctx = mrt.Context(device=0, flags=flags)
+        try:
+            for sc in scenes:
+                monkeypatch.setenv("MRT_FORCE_SLICES", "1")
+                ref = gpu_render(ctx, sc)
+                assert ref["stats"].prim_slices == 1
+                seen = {1}
+                for n in (2, 3, 5, 16, 64, 1000):
+                    monkeypatch.setenv("MRT_FORCE_SLICES", str(n))
+                    r = gpu_render(ctx, sc)
+                    seen.add(r["stats"].prim_slices)
+                    assert_same_hits(r, ref)
+                    assert np.array_equal(r["rgba"], ref["rgba"]), (flags, n)
+                assert len(seen) >= 4, seen          # the override did cut the list in different ways
+                monkeypatch.delenv("MRT_FORCE_SLICES")
+                r = gpu_render(ctx, sc)
+                assert_same_hits(r, ref)
+                assert np.array_equal(r["rgba"], ref["rgba"])
+        finally:
+            ctx.close()
+
+
 def test_render_is_deterministic(gpu_ctx, mrt):
     ls = mrt.LoadedScene(text=mkscene.teatime(1280, 720)).copy()
     a = gpu_render(gpu_ctx, ls)
