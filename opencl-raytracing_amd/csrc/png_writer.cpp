@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -103,8 +104,15 @@ extern "C" int mrt_write_png_rgb(const char* path, const uint8_t* rgba, uint32_t
         stripes[k].row_begin = k * rows_per;
         stripes[k].row_end = std::min(yres, (k + 1) * rows_per);
     }
+    // At most 16 threads (a one-GPU share of a node's cores) unless MRT_PNG_THREADS says otherwise:
+    // a caller who has the whole node (the frame of eight GPUs) can give the encoder more.
     unsigned hw = std::thread::hardware_concurrency();
-    unsigned n_threads = std::max(1u, std::min<unsigned>(std::min(hw ? hw : 1u, 16u), n_stripes));
+    unsigned cap = 16u;
+    if (const char* env = std::getenv("MRT_PNG_THREADS")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1 && v <= 1024) cap = static_cast<unsigned>(v);
+    }
+    unsigned n_threads = std::max(1u, std::min<unsigned>(std::min(hw ? hw : 1u, cap), n_stripes));
     std::vector<std::thread> pool;
     for (unsigned t = 0; t < n_threads; ++t) {
         pool.emplace_back([&, t]() {
