@@ -40,6 +40,14 @@ int main(int argc, char **argv)
     CHECK(offsetof(mrt_cl_intersect, color) == 64);
     CHECK(offsetof(mrt_cl_phong, ambient_color) == 12);
     CHECK(mrt_abi_version() == MRT_ABI_VERSION);
+    /* configuration structs of the handles: plain 32-bit fields in this order */
+    CHECK(sizeof(mrt_config) == 8);
+    CHECK(sizeof(mrt_sequence_config) == 12 && offsetof(mrt_sequence_config, in_flight) == 8);
+    CHECK(offsetof(mrt_camera, xres) == 48 && offsetof(mrt_camera, projection) == 72 && sizeof(mrt_camera) == 80);
+    /* no GPU needed to be told so: NULL handles are refused, not dereferenced */
+    CHECK(mrt_sequence_wait(NULL) == MRT_ERR_INVALID);
+    CHECK(mrt_sequence_submit_host(NULL, NULL, NULL) == MRT_ERR_INVALID);
+    CHECK(mrt_sequence_in_flight(NULL) == 0);
 
     if (argc > 1) {
         mrt_loaded_scene *ls = NULL;
