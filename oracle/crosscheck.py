@@ -57,7 +57,8 @@ def ortho_teatime(xres, yres):
 def compare(sc, rows_list, chunk=32, threads=8):
     """Oracle vs model on the given row ranges; counts summed over the ranges."""
     tot = {"pixels": 0, "hit_pixels": 0, "id_mismatches": 0, "beyond_1lsb": 0, "beyond_1lsb_off_edge": 0,
-           "max_rel_t_diff_same_winner": 0.0}
+           "beyond_1lsb_off_edge_on_triangles": 0, "max_rel_t_diff_same_winner": 0.0}
+    n_spheres = sc.struct.n_spheres
     for (y0, y1) in rows_list:
         # one row above and below so that the edge mask sees the neighbours
         a0, a1 = max(0, y0 - 1), min(sc.struct.yres, y1 + 1)
@@ -77,6 +78,8 @@ def compare(sc, rows_list, chunk=32, threads=8):
         tot["id_mismatches"] += int((s["ids"][sl] != oi[sl]).sum())
         tot["beyond_1lsb"] += int(bad.sum())
         tot["beyond_1lsb_off_edge"] += int((bad & ~em[sl]).sum())
+        # (off an edge the two disagree only on spheres: FP32 b*b - a*c, kernel.cl:254, cancels)
+        tot["beyond_1lsb_off_edge_on_triangles"] += int((bad & ~em[sl] & (oi[sl] >= n_spheres)).sum())
     return tot
 
 
@@ -93,6 +96,11 @@ def cases():
     yield "soup_ortho_1024x1024_rows", soup_o, [(y, y + 1) for y in (3, 130, 257, 384, 511, 640, 770, 900, 1020)]
     # an eighth of the benchmark frame: ten rows out of every eighty, top to bottom
     yield "teatime_3840x2160_row_blocks", t4k, [(y, y + 10) for y in range(0, 2160, 80)]
+    # the two large benchmark frames at their own size: rows of teatime at 7680 x 4320 and of the soup at 16384^2
+    t8k = scene_py.load_scene(ROOT / "scenes" / "teatime.json", xres=7680, yres=4320,
+                              viewport=(-7680 / 4320, 7680 / 4320, 1.0, -1.0))
+    yield "teatime_7680x4320_rows", t8k, [(y, y + 1) for y in (1300, 1700, 2000, 2160, 2400, 2800, 3200)]
+    yield "soup_16384x16384_rows", soup_scene(16384, 16384, "persp"), [(y, y + 1) for y in (2049, 8191, 12001)]
 
 
 if __name__ == "__main__":
