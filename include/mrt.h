@@ -127,6 +127,7 @@ enum {
      * pixels out).  Both set: MRT_ERR_INVALID. */
     MRT_FLAG_TRACE_NARROW = 1u << 6,
     MRT_FLAG_TRACE_WIDE = 1u << 7
+    /* (bit 30 is reserved: the library marks the slots of an mrt_sequence with it) */
 };
 
 typedef struct mrt_stats {

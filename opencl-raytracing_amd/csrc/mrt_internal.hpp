@@ -6,12 +6,13 @@
 
 // Context flags that are not part of the public ABI: the screen-space culling
 // kernels of a brute-force context, reachable only through mrt_accel_* (which
-// creates its inner context with mrt_create_internal_).  mrt_create rejects
-// them.
+// creates its inner context with mrt_create_internal_), and the mark of a
+// context that is one slot of an mrt_sequence.  mrt_create rejects them.
 enum : uint32_t {
     MRT_IFLAG_BLOCK_REJECT = 1u << 2,   // trace_kernel preceded by the 4x4 block reject
     MRT_IFLAG_SCREEN_CULL = 1u << 4,    // cull_trace_kernel: 32x32 tile cull
-    MRT_IFLAG_MASK = MRT_IFLAG_BLOCK_REJECT | MRT_IFLAG_SCREEN_CULL
+    MRT_IFLAG_IN_FLIGHT = 1u << 30,     // frames of other contexts run beside this one's: fewer, longer slices
+    MRT_IFLAG_MASK = MRT_IFLAG_BLOCK_REJECT | MRT_IFLAG_SCREEN_CULL | MRT_IFLAG_IN_FLIGHT
 };
 
 extern "C" {

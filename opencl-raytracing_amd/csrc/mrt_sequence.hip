@@ -8,6 +8,7 @@
 // directly except the slots' streams; the frames are mrt_set_camera +
 // mrt_render_bands_device on the slot's context.
 #include "mrt.h"
+#include "mrt_internal.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -102,8 +103,13 @@ int mrt_sequence_create(const mrt_sequence_config* cfg, mrt_sequence** out) {
     q->slots.resize(n);
     for (uint32_t k = 0; k < n; ++k) {
         mrt_config c = {cfg ? cfg->device : -1, cfg ? cfg->flags : 0u};
+        if (c.flags & MRT_IFLAG_MASK) {
+            mrt_sequence_destroy(q);
+            return qfail(nullptr, MRT_ERR_INVALID, "reserved flag bits set in mrt_sequence_config.flags");
+        }
         if (k > 0) c.device = q->device;                 // "-1" must mean the same GPU for every slot
-        const int rc = mrt_create(&c, &q->slots[k].ctx);
+        if (n > 1) c.flags |= MRT_IFLAG_IN_FLIGHT;       // slices sized for a GPU that other frames keep full
+        const int rc = mrt_create_internal_(&c, &q->slots[k].ctx);
         if (rc != MRT_OK) {
             const std::string msg = mrt_last_error(nullptr);
             mrt_sequence_destroy(q);
