@@ -2,7 +2,7 @@
 """Throughput of the default path with one frame at a time against several frames in flight
 (one mrt_ctx and one stream per frame in flight, frames handed out in rotation).  GPU box only.
 
-usage: time_overlap.py [teatime|soup] XRES YRES [STEPS]
+usage: time_overlap.py [teatime|soup] XRES YRES [STEPS [FLAGS]]     (FLAGS: MRT_FLAG_* as an integer)
 """
 import sys
 import time
@@ -18,6 +18,7 @@ import mkscene  # noqa: E402
 mrt = mrt_pkg.load()
 kind, xres, yres = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+flags = int(sys.argv[5], 0) if len(sys.argv) > 5 else 0
 text = mkscene.teatime(xres, yres) if kind == "teatime" else mkscene.soup(xres, yres)
 scene = mrt.LoadedScene(text=text).copy()
 dev = torch.device("cuda", 0)
@@ -26,7 +27,7 @@ dev = torch.device("cuda", 0)
 def run(n_flight):
     ctxs, streams, outs = [], [], []
     for _ in range(n_flight):
-        c = mrt.Context(device=0)
+        c = mrt.Context(device=0, flags=flags)
         c.set_scene(scene)
         ctxs.append(c)
         streams.append(torch.cuda.Stream(dev))
