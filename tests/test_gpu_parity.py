@@ -707,6 +707,27 @@ def test_sequence_of_views_equals_fresh_contexts(mrt, in_flight):
     assert e.value.code == -5
 
 
+def test_sequence_slots_at_two_megapixels(gpu_ctx, mrt):
+    """The slots of a sequence choose lane shape and slice count for a GPU that other frames keep
+    full (8x4 lane blocks from 2 Mpixel, fewer slices): same bytes as a context's frame, at a size
+    where the two choices differ."""
+    sc = mrt.LoadedScene(text=mkscene.teatime(1920, 1080)).copy()
+    gpu_ctx.set_scene(sc)
+    want, st = gpu_ctx.render()
+    assert st.kernel == mrt.KERNEL_TRACE
+    seq = mrt.Sequence(device=0)
+    try:
+        seq.set_scene(sc)
+        outs = [mrt.host_array((1080, 1920, 4)) for _ in range(5)]
+        for o in outs:
+            seq.submit_host(o)
+        seq.wait()
+        for o in outs:
+            assert np.array_equal(o, want)
+    finally:
+        seq.close()
+
+
 def test_slice_and_layer_count_invariance(mrt, monkeypatch):
     """The triangle list cut into any number of slices (trace_kernel, both lane shapes) or layers
     (full_trace_kernel) gives the same winners, t and bytes as one piece: the pieces meet in the
