@@ -89,12 +89,15 @@ def cpu_baseline(sc, seconds_target=12.0):
 def profiled_counters(kernel):
     """Mean hardware counters per launch of one kernel from the newest committed rocprofv3 passes
     of this same command (profiles/rNN/teatime4k_pmc_summary.json, made by tools/profile.sh and
-    tools/summarize_profile.py), or (None, None)."""
+    tools/summarize_profile.py), or (None, None).  The summary has an entry per launch shape; the
+    one with the largest grid is a whole frame of one context, which is what the kernel times
+    quoted beside the counters are measured on."""
     for f in sorted((ROOT / "profiles").glob("r*/teatime4k_pmc_summary.json"), reverse=True):
         try:
-            for name, entry in json.loads(f.read_text()).items():
-                if kernel in name:
-                    return entry["counters_mean_per_launch"], str(f.relative_to(ROOT))
+            found = [e for name, e in json.loads(f.read_text()).items() if kernel in name]
+            if found:
+                best = max(found, key=lambda e: int(e["dispatch"]["Grid_Size"]))
+                return best["counters_mean_per_launch"], str(f.relative_to(ROOT))
         except (KeyError, ValueError):
             continue
     return None, None

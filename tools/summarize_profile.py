@@ -30,6 +30,9 @@ def main(src, dst):
             k = r["Kernel_Name"]
             if "mrt::" not in k:
                 continue
+            # one entry per launch shape: the same kernel runs with different grids (a frame of a
+            # context and a frame of a sequence slot are cut into different numbers of slices)
+            k = f"{k} [grid {r['Grid_Size']}]"
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
             meta[k] = {x: r[x] for x in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size")}
         for (k, c), v in sorted(agg.items()):
