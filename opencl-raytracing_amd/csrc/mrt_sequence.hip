@@ -101,12 +101,12 @@ int mrt_sequence_create(const mrt_sequence_config* cfg, mrt_sequence** out) {
     KeepDevice keep;
     mrt_sequence* q = new mrt_sequence();
     q->slots.resize(n);
+    if (cfg && (cfg->flags & MRT_IFLAG_MASK)) {
+        mrt_sequence_destroy(q);
+        return qfail(nullptr, MRT_ERR_INVALID, "reserved flag bits set in mrt_sequence_config.flags");
+    }
     for (uint32_t k = 0; k < n; ++k) {
         mrt_config c = {cfg ? cfg->device : -1, cfg ? cfg->flags : 0u};
-        if (c.flags & MRT_IFLAG_MASK) {
-            mrt_sequence_destroy(q);
-            return qfail(nullptr, MRT_ERR_INVALID, "reserved flag bits set in mrt_sequence_config.flags");
-        }
         if (k > 0) c.device = q->device;                 // "-1" must mean the same GPU for every slot
         if (n > 1) c.flags |= MRT_IFLAG_IN_FLIGHT;       // slices sized for a GPU that other frames keep full
         const int rc = mrt_create_internal_(&c, &q->slots[k].ctx);
@@ -121,13 +121,17 @@ int mrt_sequence_create(const mrt_sequence_config* cfg, mrt_sequence** out) {
             if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
             q->device = dev;
         }
-        hipError_t e = hipSetDevice(q->device);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&q->slots[k].stream, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            const std::string msg = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-            mrt_sequence_destroy(q);
-            return qfail(nullptr, MRT_ERR_HIP, msg);
-        }
+    }
+    // The slots' streams are made one right after the other: the runtime deals its few hardware
+    // queues out to streams in the order they are made, and two slots that shared a queue would
+    // run their frames one behind the other.
+    hipError_t e = hipSetDevice(q->device);
+    for (uint32_t k = 0; k < n && e == hipSuccess; ++k)
+        e = hipStreamCreateWithFlags(&q->slots[k].stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        const std::string msg = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        mrt_sequence_destroy(q);
+        return qfail(nullptr, MRT_ERR_HIP, msg);
     }
     *out = q;
     return MRT_OK;
