@@ -51,7 +51,7 @@ struct mrt_sequence {
     uint64_t view_serial = 0;
     uint64_t next = 0;               // frames submitted so far
     // mrt_sequence_submit_host: 2 x in_flight device buffers, taken in rotation, and the stream
-    // the copies to the host run on (made on first use)
+    // the copies to the host run on
     std::vector<HostLane> lanes;
     hipStream_t copy_stream = nullptr;
     uint64_t host_next = 0;
@@ -128,6 +128,8 @@ int mrt_sequence_create(const mrt_sequence_config* cfg, mrt_sequence** out) {
     hipError_t e = hipSetDevice(q->device);
     for (uint32_t k = 0; k < n && e == hipSuccess; ++k)
         e = hipStreamCreateWithFlags(&q->slots[k].stream, hipStreamNonBlocking);
+    // ... and the stream mrt_sequence_submit_host copies on right behind them, for the same reason
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&q->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         const std::string msg = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         mrt_sequence_destroy(q);
@@ -216,8 +218,7 @@ int mrt_sequence_submit_host(mrt_sequence* q, const mrt_camera* view, uint8_t* h
         if (e_ != hipSuccess) return qfail(q, MRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
     QHIP(hipSetDevice(q->device));
-    if (!q->copy_stream) {
-        QHIP(hipStreamCreateWithFlags(&q->copy_stream, hipStreamNonBlocking));
+    if (q->lanes.empty()) {
         q->lanes.resize(2 * q->slots.size());
         for (HostLane& l : q->lanes) {
             QHIP(hipEventCreateWithFlags(&l.rendered, hipEventDisableTiming));
