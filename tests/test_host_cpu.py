@@ -4,6 +4,7 @@ partition helpers, the PNG writer and the CLI contract (mrraytracer.cpp:23-148).
 import ctypes
 import json
 import subprocess
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -247,3 +248,19 @@ def test_cli_scene_summary_format(tmp_path):
         assert r.returncode == 1 and "render failed" in r.stderr
     else:
         assert r.returncode == 0 and r.stdout.endswith("done\n\n")
+
+
+def test_committed_profile_feeds_the_bench_line():
+    """The counters bench.py quotes beside its timings come from the committed rocprofv3 summary:
+    it must hold both render kernels, with the instruction counts the documentation states."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    full, src = bench.profiled_counters("mrt::full_trace_kernel")
+    assert src and src.startswith("profiles/")
+    pairs = 3840 * 2160 * 4034
+    assert 20.0 < full["SQ_INSTS_VALU"] * 64 / pairs < 28.0            # instructions per (ray, primitive) pair
+    assert bench.profiled_traffic(full) > 0
+    default, _ = bench.profiled_counters("mrt::trace_kernel")
+    assert 1.5 < default["SQ_INSTS_VALU"] * 64 / pairs < 3.0
+    assert default["SQ_WAVES"] == 130560                                # a context's 4K frame in 32 slices
+    assert bench.algorithmic_flops(type("S", (), {"n_tris": 4032, "n_spheres": 2}), 3840 * 2160) == 1505267712000.0
