@@ -667,7 +667,11 @@ int mrt_accel_set_camera(mrt_accel* a, const mrt_camera* camera) {
         AHIP_TRY(a, hipStreamWaitEvent((hipStream_t)mrt_ctx_stream_(a->base), a->frame_done, 0));
     }
     int rc = mrt_set_camera(a->base, camera);
-    if (rc != MRT_OK) return base_failed(a, rc);
+    if (rc != MRT_OK) {
+        // a camera the base context refused outright (bad argument) has changed nothing
+        a->have_scene = rc != MRT_ERR_HIP;
+        return base_failed(a, rc);
+    }
     if (a->method == MRT_ACCEL_GRID) {
         AccelDeviceGuard guard(a->device);
         AHIP_TRY(a, guard.err);

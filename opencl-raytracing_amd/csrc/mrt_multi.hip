@@ -283,7 +283,11 @@ int mrt_multi_set_camera(mrt_multi* m, const mrt_camera* camera) {
     m->have_scene = false;
     for (size_t r = 0; r < m->ranks.size(); ++r) {
         const int rc = mrt_set_camera(m->ranks[r].ctx, camera);
-        if (rc != MRT_OK) return mfail(m, rc, "rank " + std::to_string(r) + ": " + mrt_last_error(m->ranks[r].ctx));
+        if (rc != MRT_OK) {
+            // a camera rank 0 refused outright (bad argument) has changed nothing anywhere
+            m->have_scene = r == 0 && rc != MRT_ERR_HIP;
+            return mfail(m, rc, "rank " + std::to_string(r) + ": " + mrt_last_error(m->ranks[r].ctx));
+        }
     }
     m->xres = camera->xres; m->yres = camera->yres;
     CurrentDevice keep;

@@ -210,6 +210,15 @@ def test_accel_api_errors(mrt):
             torch.cuda.synchronize()
             want, _ = a.render()
             assert np.array_equal(buf.cpu().numpy().reshape(400, 400, 4), want)
+            # a camera that is refused outright leaves the handle as it was
+            bad = ls.copy()
+            bad.struct.projection = 9
+            with pytest.raises(mrt.MrtError) as e:
+                a.set_camera(bad)
+            assert e.value.code == -1
+            a.xres, a.yres = 400, 400
+            again, _ = a.render()
+            assert np.array_equal(again, want)
         finally:
             a.close()
 
