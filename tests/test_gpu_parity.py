@@ -918,6 +918,44 @@ def test_cli_end_to_end(tmp_path):
         check(rgba, g["rgba"], g["ids"])
 
 
+def test_turntable_example(tmp_path, mrt):
+    """mrturntable: a C++ client of mrt_sequence_submit_host.  The middle frame of an odd number
+    of frames is the scene's own view -- the bytes mrraytracer writes -- and every other frame is
+    what a context renders for that frame's camera (the basis panned about v)."""
+    import json
+    from PIL import Image
+    tt = ROOT / "opencl-raytracing_amd" / "mrturntable"
+    cli = ROOT / "opencl-raytracing_amd" / "mrraytracer"
+    scene = SCENES / "teatime.json"
+    r = subprocess.run([str(tt), str(scene), str(tmp_path / "v"), "5", "40"], capture_output=True, text=True,
+                       env=dict(__import__("os").environ, MRT_STATS="1", MRT_IN_FLIGHT="3"))
+    assert r.returncode == 0, r.stderr
+    st = json.loads(r.stderr.strip().splitlines()[-1])
+    assert st["frames"] == 5 and st["in_flight"] == 3 and st["xres"] == 400
+    one = tmp_path / "one.png"
+    assert subprocess.run([str(cli), str(scene), str(one)], capture_output=True).returncode == 0
+    assert (tmp_path / "v002.png").read_bytes() == one.read_bytes()
+    ls = mrt.LoadedScene(path=scene)
+    base = ls.copy()
+    info_u, info_w = np.array(list(ls.info.u), np.float64), np.array(list(ls.info.w), np.float64)
+    ctx = mrt.Context(device=0)
+    try:
+        ctx.set_scene(base)
+        for k in (0, 1, 3, 4):
+            a = (k / 4 - 0.5) * 40.0 * 3.14159265358979323846 / 180.0       # as the example forms it
+            view = base.with_resolution(400, 400)
+            for i in range(3):
+                view.struct.u[i] = np.float32(np.cos(a) * info_u[i] - np.sin(a) * info_w[i])
+                view.struct.w[i] = np.float32(np.sin(a) * info_u[i] + np.cos(a) * info_w[i])
+            ctx.set_camera(view)
+            want, _ = ctx.render()
+            with Image.open(tmp_path / f"v{k:03d}.png") as im:
+                assert np.array_equal(np.asarray(im), want[..., :3]), k
+    finally:
+        ctx.close()
+    assert subprocess.run([str(tt), str(scene), str(tmp_path / "v"), "0"], capture_output=True).returncode == 255
+
+
 def test_dist_cli_two_ranks_on_one_gpu(tmp_path):
     """mrraytracer_dist.py (one process per GPU, bands gathered to rank 0) with two ranks that
     share GPU 0 and gather over gloo: same stdout contract and the same pixels as the binary."""
