@@ -706,9 +706,12 @@ class _PinnedBlock:
         self.ptr = p.value
 
     def __del__(self):
-        if getattr(self, "ptr", None):
-            lib().mrt_host_free(self.ptr)
-            self.ptr = None
+        try:
+            if getattr(self, "ptr", None):
+                lib().mrt_host_free(self.ptr)
+                self.ptr = None
+        except Exception:      # interpreter shutdown: the module's globals may be gone already
+            pass
 
 
 def host_array(shape, dtype=np.uint8):
