@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 5
+#define MRT_ABI_VERSION 6
 
 typedef enum mrt_status {
     MRT_OK = 0,
@@ -507,10 +507,25 @@ int mrt_stage_ortho_viewrays(mrt_ctx *ctx, const mrt_cl_cam *camera, const mrt_c
 int mrt_stage_persp_viewrays(mrt_ctx *ctx, const mrt_cl_cam *camera, const mrt_cl_float2 *uv, int n,
                              float focal_length, mrt_cl_ray *rays_out);
 /* kernel `intersections` (kernel.cl:305-379) / cl_intersect (CLHelpers.hpp:191):
- * arbitrary rays against arbitrary objects, closest hit in (t_lower, t_upper). */
+ * arbitrary rays (an origin and a direction each) against arbitrary objects
+ * (spheres and triangles in any order), closest hit in (t_lower, t_upper), the
+ * lower object index among equal t.  Every (ray, object) pair is tested: rays
+ * go through registers eight to a lane, objects through LDS in chunks, and the
+ * object list is cut into slices (grid layers) that meet in one 64-bit (t, index)
+ * key per ray, so that the reference's own 160000 rays fill the GPU.  Per
+ * (ray, triangle) pair the kernel forms a - origin, one cross product and the
+ * four determinants of tri_intersect's Cramer solve (kernel.cl:187-213) with
+ * fused multiply-adds, as a conservative filter; the pairs it cannot rule out
+ * (about one in two thousand on the shipped mesh) and every pair of a ray with
+ * non-finite or huge components run the reference's own unfused arithmetic,
+ * which decides.  Bit-identical records to the per-ray loop of the reference. */
 int mrt_stage_intersect(mrt_ctx *ctx, const mrt_cl_object *objects, int n_objects,
                         const mrt_cl_ray *rays, int n_rays, float t_upper_bound,
                         float t_lower_bound, mrt_cl_intersect *out);
+/* Device time (HIP events, milliseconds) of the kernels of the last
+ * mrt_stage_intersect call on ctx, without the copies either side: what the
+ * reference never measures (CLHelpers.hpp:230-236 only waits for the queue). */
+double mrt_stage_last_kernel_ms(const mrt_ctx *ctx);
 /* kernel `flat_shader` (kernel.cl:381-396) / cl_flat_shader (CLHelpers.hpp:239). */
 int mrt_stage_flat_shader(mrt_ctx *ctx, const mrt_cl_intersect *xsects, int n, mrt_cl_rgb background,
                           mrt_cl_rgb *out);

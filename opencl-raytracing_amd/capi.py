@@ -26,7 +26,7 @@ RESERVED_FLAG_BITS = (1 << 2) | (1 << 4) | (1 << 30)          # mrt_create refus
 KERNEL_TRACE, KERNEL_TRACE_BLOCK, KERNEL_CULL, KERNEL_FULL, KERNEL_GRID, KERNEL_TRACE_WIDE = 0, 1, 2, 3, 4, 5    # mrt_stats.kernel
 ACCEL_GRID, ACCEL_TILE_CULL, ACCEL_BLOCK_REJECT = 0, 1, 2                                 # mrt_accel_config.method
 ACCEL_METHODS = {"grid": ACCEL_GRID, "cull": ACCEL_TILE_CULL, "block": ACCEL_BLOCK_REJECT}
-ABI_VERSION = 5
+ABI_VERSION = 6
 PROJ_ORTHO, PROJ_PERSP = 0, 1
 SHADER_FLAT, SHADER_PHONG = 0, 1
 
@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "mrt_bands_to_image", "mrt_scene_load_file", "mrt_scene_load_text", "mrt_scene_view",
     "mrt_scene_info_view", "mrt_scene_free", "mrt_write_png_rgb", "mrt_stage_uv",
     "mrt_stage_ortho_viewrays", "mrt_stage_persp_viewrays", "mrt_stage_intersect",
-    "mrt_stage_flat_shader", "mrt_stage_phong_shader", "mrt_host_alloc", "mrt_host_free",
+    "mrt_stage_flat_shader", "mrt_stage_phong_shader", "mrt_stage_last_kernel_ms", "mrt_host_alloc", "mrt_host_free",
     "mrt_render_bands_device_noalloc",
     "mrt_multi_create", "mrt_multi_destroy", "mrt_multi_last_error", "mrt_multi_world", "mrt_multi_gather",
     "mrt_multi_note", "mrt_multi_set_scene", "mrt_multi_set_camera", "mrt_multi_render_rgba8",
@@ -282,6 +282,8 @@ def lib():
     L._Rgb = _Rgb
     L.mrt_stage_flat_shader.argtypes = [vp, vp, C.c_int, _Rgb, vp]
     L.mrt_stage_phong_shader.argtypes = [vp, vp, vp, C.c_int, _Rgb, vp, vp, C.c_int, vp]
+    L.mrt_stage_last_kernel_ms.argtypes = [vp]
+    L.mrt_stage_last_kernel_ms.restype = C.c_double
     _lib = L
     return L
 
@@ -471,6 +473,10 @@ class Context:
                                               len(objects), rays.ctypes.data, len(rays), float(t_upper),
                                               float(t_lower), xs.ctypes.data))
         return xs
+
+    def stage_kernel_ms(self):
+        """Device time of the kernels of the last stage_intersect call (HIP events)."""
+        return float(lib().mrt_stage_last_kernel_ms(self._h))
 
     def stage_flat(self, xs, background, out=None):
         res = np.zeros(len(xs), CL_DTYPES["rgb"]) if out is None else out

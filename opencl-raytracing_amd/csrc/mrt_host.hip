@@ -132,8 +132,10 @@ struct mrt_ctx {
     uint32_t last_pitch = 0;                 // pitch of the (t, id) planes the last frame wrote
     uint32_t frame_tag = 0;                  // tag of the last frame that used the tile flags
     // mrt_stage_*: device staging buffers that grow on demand and live as long as the ctx
-    void* stage_buf[3] = {nullptr, nullptr, nullptr};
-    size_t stage_cap[3] = {0, 0, 0};
+    static constexpr int kStageSlots = 5;
+    void* stage_buf[kStageSlots] = {};
+    size_t stage_cap[kStageSlots] = {};
+    double stage_kernel_ms = 0.0;            // device time of the kernels of the last mrt_stage_intersect
     hipEvent_t frame_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool frame_pending = false;
@@ -528,7 +530,7 @@ extern "C" int mrt_stage_device_(const mrt_ctx* ctx) { return ctx ? ctx->device 
 // Staging buffer `slot` of the ctx with room for `bytes` (the ctx's GPU must be current); the
 // previous contents are not kept when it grows.  nullptr + the ctx's error on failure.
 extern "C" void* mrt_stage_buffer_(mrt_ctx* ctx, int slot, size_t bytes) {
-    if (!ctx || slot < 0 || slot >= 3) return nullptr;
+    if (!ctx || slot < 0 || slot >= mrt_ctx::kStageSlots) return nullptr;
     if (bytes == 0) bytes = 1;
     if (bytes > ctx->stage_cap[slot]) {
         // an earlier stage call may still be reading the old buffer on the ctx's stream
@@ -546,6 +548,10 @@ extern "C" void* mrt_stage_buffer_(mrt_ctx* ctx, int slot, size_t bytes) {
     }
     return ctx->stage_buf[slot];
 }
+// The ctx's timing events (0, 1): the stage calls block, so they never overlap a timed frame.
+extern "C" void* mrt_stage_event_(mrt_ctx* ctx, int which) { return (void*)ctx->ev[which & 1]; }
+extern "C" void mrt_stage_set_kernel_ms_(mrt_ctx* ctx, double ms) { ctx->stage_kernel_ms = ms; }
+extern "C" double mrt_stage_get_kernel_ms_(const mrt_ctx* ctx) { return ctx->stage_kernel_ms; }
 // Shared with mrt_accel.hip (mrt_internal.hpp).
 extern "C" const mrt::RenderParams* mrt_ctx_params_(const mrt_ctx* ctx) { return &ctx->params; }
 extern "C" void* mrt_ctx_stream_(const mrt_ctx* ctx) { return (void*)ctx->stream; }
@@ -616,7 +622,7 @@ void mrt_destroy(mrt_ctx* ctx) {
     if (ctx->d_tile_flags) (void)hipFree(ctx->d_tile_flags);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
-    for (int k = 0; k < 3; ++k) if (ctx->stage_buf[k]) (void)hipFree(ctx->stage_buf[k]);
+    for (int k = 0; k < mrt_ctx::kStageSlots; ++k) if (ctx->stage_buf[k]) (void)hipFree(ctx->stage_buf[k]);
     for (int k = 0; k < 3; ++k) if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->frame_done) (void)hipEventDestroy(ctx->frame_done);
     if (ctx->records_ready) (void)hipEventDestroy(ctx->records_ready);

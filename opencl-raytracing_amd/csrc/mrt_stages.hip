@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,6 +24,9 @@ extern "C" int mrt_stage_set_error_(mrt_ctx* ctx, int code, const char* msg);
 extern "C" int mrt_stage_device_(const mrt_ctx* ctx);
 extern "C" void* mrt_stage_buffer_(mrt_ctx* ctx, int slot, size_t bytes);
 extern "C" void* mrt_ctx_stream_(const mrt_ctx* ctx);
+extern "C" void* mrt_stage_event_(mrt_ctx* ctx, int which);
+extern "C" void mrt_stage_set_kernel_ms_(mrt_ctx* ctx, double ms);
+extern "C" double mrt_stage_get_kernel_ms_(const mrt_ctx* ctx);
 
 namespace mrt {
 
@@ -53,49 +57,373 @@ __global__ void stage_rays_kernel(CamK c, const float2* __restrict__ uv, int n, 
     rays[2 * (size_t)i + 1] = make_float4(d.x, d.y, d.z, 0.f);
 }
 
-// Compact object record: kind in geo[0].w (0 sphere, 1 triangle).
-//   sphere   geo[0] = (cx, cy, cz, kind) geo[1] = (r, -, -, -)
-//   triangle geo[0] = (ax, ay, az, kind) geo[1] = (bx, by, bz, -) geo[2] = (cx, cy, cz, -)
+// ---------------------------------------------------------------------------
+// kernel `intersections` (kernel.cl:305-379) for ARBITRARY rays: every ray
+// brings its own origin and direction, the caller brings the t range.
+//
+// Closest hit = the smallest accepted t, the lowest object index among equal t
+// (the reference walks the objects in order and keeps a hit only on a strict
+// "<", kernel.cl:326,344), over the pairs with t_lower < t < t_upper.  That is
+// independent of the order in which pairs are evaluated, so the object list is
+// cut into slices (blockIdx.z), every slice of every ray block is a wave of its
+// own, and the slices meet in one 64-bit key per ray, (t, object index), under
+// atomicMin.
+//
+// Object record (host side, 3 x float4 per object, in the caller's order):
+//   sphere   geo[0] = (cx, cy, cz, 0) geo[1] = (r, -, -, -)
+//   triangle geo[0] = (ax, ay, az, 1) geo[1] = (bx, by, bz, -) geo[2] = (cx, cy, cz, -)
+//
+// Triangles.  tri_intersect (kernel.cl:197-235) solves by Cramer's rule: det,
+// Nb, Ng, Nt, then beta = Nb/det, gamma = Ng/det, t = Nt/det and the range
+// tests.  With s1 = a - b, s2 = a - c, n = s1 x s2 (per triangle), sol = a - o
+// and q = d x sol (per pair):
+//     det = d . n     Nt = sol . n     Nb = s2 . q     Ng = -s1 . q
+// One vector subtraction, one cross product and four dot products per pair,
+// evaluated with fused multiply-adds -- a conservative filter, never the
+// decision: a hit needs Nb, Ng and W = det - Nb - Ng (and Nt, when t_lower >= 0)
+// to have the sign of det, and since det = Nb + Ng + W that is "all of one
+// sign".  The fused values differ from the reference's unfused ones by at most
+// 10 u P (u = 2^-24, P the sum of the absolute values of the six products of
+// the determinant); prep_general_records bounds P per triangle over all rays
+// of the call (general_ray_bounds), takes M = 32 u (sum of the four P) plus the
+// band that keeps a quotient which would round to -0, and the kernel starts
+// every fma chain at +M: X = value + M.  A pair goes on to the reference
+// arithmetic (tri_exact, from the original vertices) unless some X is negative
+// AND some X exceeds 2M; on the shipped mesh about one pair in two thousand
+// does.  Rays with a non-finite or huge component ("wild") run the reference
+// arithmetic for every object, as do triangles whose products may overflow.
+//
+// Spheres: the discriminant of circle_intersect (kernel.cl:248-254) in the
+// reference's own operation order for every pair; sqrt and the division only
+// where it is not negative.
+// ---------------------------------------------------------------------------
 struct HitOut { float4 loc_t; float4 n_id; };
 
-__global__ void stage_intersect_kernel(const float4* __restrict__ geo, int n_objects,
-                                       const float4* __restrict__ rays, int n_rays, float t_upper,
-                                       float t_lower, HitOut* __restrict__ out) {
+constexpr int kGenRays = 8;              // rays per lane
+constexpr int kGenThreads = 256;
+constexpr int kGenBlockRays = kGenThreads * kGenRays;
+constexpr int kGenChunk = 256;           // triangle records per LDS chunk (4 float4 each: 16 KiB)
+constexpr int kGenRecFloat4 = 4;
+constexpr int kGenSphFloat4 = 2;         // (cx, cy, cz, r) (object index, -, -, -)
+constexpr int kGenQueue = 64 + kGenRays * 64;   // (ray, object) pairs awaiting the reference arithmetic, per wave
+constexpr float kWildLimit = 0x1p60f;    // rays with a component at or beyond this (or NaN) are "wild"
+
+// Order-preserving map of a float to an unsigned integer (negative t is legal when t_lower < 0).
+__device__ __forceinline__ uint32_t ordered_bits(float t) {
+    const uint32_t b = __float_as_uint(t + 0.0f);             // -0 and +0 compare equal: one key for both
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ bool is_wild(float4 ro, float4 rd) {
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(ro.x), fabsf(ro.y)), fmaxf(fabsf(ro.z), fabsf(rd.x))),
+                          fmaxf(fabsf(rd.y), fabsf(rd.z)));
+    // fmaxf drops NaNs: test every component on its own
+    const bool nan = ro.x != ro.x || ro.y != ro.y || ro.z != ro.z || rd.x != rd.x || rd.y != rd.y || rd.z != rd.z;
+    return nan || !(m < kWildLimit);
+}
+
+// Per component, the largest |origin| and |direction| over the rays that are not wild, as the
+// bit patterns of non-negative floats under atomicMax (bounds[0..2] origin, [3..5] direction):
+// four rays per thread, one set of atomics per block.
+__global__ __launch_bounds__(256) void general_ray_bounds(const float4* __restrict__ rays, int n_rays,
+                                                          uint32_t* __restrict__ bounds) {
+    __shared__ float s_m[4][6];
+    float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rays; i += gridDim.x * blockDim.x) {
+        const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
+        if (is_wild(ro, rd)) continue;
+        m[0] = fmaxf(m[0], fabsf(ro.x)); m[1] = fmaxf(m[1], fabsf(ro.y)); m[2] = fmaxf(m[2], fabsf(ro.z));
+        m[3] = fmaxf(m[3], fabsf(rd.x)); m[4] = fmaxf(m[4], fabsf(rd.y)); m[5] = fmaxf(m[5], fabsf(rd.z));
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float v = m[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const float v = fmaxf(fmaxf(s_m[0][threadIdx.x], s_m[1][threadIdx.x]), fmaxf(s_m[2][threadIdx.x], s_m[3][threadIdx.x]));
+        if (v > 0.0f) atomicMax(&bounds[threadIdx.x], __float_as_uint(v));
+    }
+}
+
+namespace {
+// a x b with one rounded product and one fused multiply-add per component.
+__device__ __forceinline__ F3 cross_fma(F3 a, F3 b) {
+    return mk3(__builtin_fmaf(a.y, b.z, -(a.z * b.y)),
+               __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+               __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+// a . b + start as a chain of three fused multiply-adds.
+__device__ __forceinline__ float dot_fma(F3 a, F3 b, float start) {
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, __builtin_fmaf(a.x, b.x, start)));
+}
+// Sum of the absolute values of the six products of det3(a, b, c), for vectors of magnitudes.
+__device__ __forceinline__ double perm_abs(double ax, double ay, double az, double bx, double by, double bz,
+                                           double cx, double cy, double cz) {
+    return ax * (by * cz + bz * cy) + ay * (bx * cz + bz * cx) + az * (bx * cy + by * cx);
+}
+// x (positive) as a float that is not below it.
+__device__ __forceinline__ float round_up_to_float(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = __uint_as_float(__float_as_uint(f) + 1u);
+    return f;
+}
+}  // namespace
+
+// Filter records of general_intersect_kernel, four float4 per triangle, in list order:
+//   (a | M) (n | 3M) (s2 | 2M) (-s1 | object index)
+__global__ void prep_general_records(const float4* __restrict__ geo, const uint32_t* __restrict__ tri_objs,
+                                     int n_tri, const uint32_t* __restrict__ bounds, float4* __restrict__ rec) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_tri) return;
+    const uint32_t obj = tri_objs[k];
+    const float4 va = geo[3 * (size_t)obj], vb = geo[3 * (size_t)obj + 1], vc = geo[3 * (size_t)obj + 2];
+    const F3 a = mk3(va.x, va.y, va.z);
+    const F3 s1 = sub3(a, mk3(vb.x, vb.y, vb.z));            // kernel.cl:204-205, as the reference rounds them
+    const F3 s2 = sub3(a, mk3(vc.x, vc.y, vc.z));
+    const F3 n = cross_fma(s1, s2);
+    // magnitudes, with room for the rounding of a - o
+    const double ox = 1.01 * (double)__uint_as_float(bounds[0]), oy = 1.01 * (double)__uint_as_float(bounds[1]),
+                 oz = 1.01 * (double)__uint_as_float(bounds[2]);
+    const double dx = 1.01 * (double)__uint_as_float(bounds[3]), dy = 1.01 * (double)__uint_as_float(bounds[4]),
+                 dz = 1.01 * (double)__uint_as_float(bounds[5]);
+    const double a1x = fabs((double)s1.x), a1y = fabs((double)s1.y), a1z = fabs((double)s1.z);
+    const double a2x = fabs((double)s2.x), a2y = fabs((double)s2.y), a2z = fabs((double)s2.z);
+    const double sx = 1.01 * fabs((double)a.x) + ox, sy = 1.01 * fabs((double)a.y) + oy, sz = 1.01 * fabs((double)a.z) + oz;
+    const double p_det = perm_abs(a1x, a1y, a1z, a2x, a2y, a2z, dx, dy, dz);
+    const double p_b = perm_abs(sx, sy, sz, a2x, a2y, a2z, dx, dy, dz);
+    const double p_g = perm_abs(a1x, a1y, a1z, sx, sy, sz, dx, dy, dz);
+    const double p_t = perm_abs(a1x, a1y, a1z, a2x, a2y, a2z, sx, sy, sz);
+    const double big = fmax(fmax(fmax(a1x, a1y), fmax(a1z, a2x)), fmax(fmax(a2y, a2z), fmax(fmax(sx, sy), fmax(sz, fmax(dx, fmax(dy, dz))))));
+    // |quotient| < 2^-149 rounds to -0, which passes the reference's "< 0"; products in the
+    // denormal range are off by 2^-150 absolutely, scaled by the factor they meet next
+    const double band = p_det * 0x1p-100 + 64.0 * 0x1p-149 * (1.0 + big);
+    const double p_all = p_det + p_b + p_g + p_t;
+    const double margin = (32.0 / 16777216.0) * p_all + band;
+    float4 r0, r1, r2, r3;
+    if (p_all < 1e36 && margin < 1e36) {                      // false for NaN too
+        const float m = round_up_to_float(margin);
+        r0 = make_float4(a.x, a.y, a.z, m);
+        r1 = make_float4(n.x, n.y, n.z, round_up_to_float(3.0 * (double)m));
+        r2 = make_float4(s2.x, s2.y, s2.z, 2.0f * m);
+        r3 = make_float4(-s1.x, -s1.y, -s1.z, 0.f);
+    } else {
+        // The margin cannot be bounded: a record every ray passes (all products zero: X = M = 1).
+        r0 = make_float4(0.f, 0.f, 0.f, 1.0f);
+        r1 = make_float4(0.f, 0.f, 0.f, 3.0f);
+        r2 = make_float4(0.f, 0.f, 0.f, 2.0f);
+        r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    r3.w = __uint_as_float(obj);
+    rec[(size_t)k * kGenRecFloat4 + 0] = r0;
+    rec[(size_t)k * kGenRecFloat4 + 1] = r1;
+    rec[(size_t)k * kGenRecFloat4 + 2] = r2;
+    rec[(size_t)k * kGenRecFloat4 + 3] = r3;
+}
+
+// HAS_T: t_lower >= 0, so an accepted t is positive and Nt takes part in the sign test.
+//
+// The pairs the filter cannot rule out are rare and scattered over lanes and rays, so they are
+// not tested where they are found: the wave appends (ray, object) to a queue of its own in LDS
+// and, whenever 64 are waiting (and once more at the end), every lane takes one entry, reads its
+// ray and its object from memory and runs the reference arithmetic -- all 64 lanes busy, nothing
+// held in registers while the filter loop runs.
+template <bool HAS_T>
+__global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
+    const float4* __restrict__ rays, int n_rays, const float4* __restrict__ tri_rec, int n_tri, int tris_per_slice,
+    const float4* __restrict__ sph_rec, int n_sph, int sph_per_slice, const float4* __restrict__ geo,
+    float t_upper, float t_lower, unsigned long long* __restrict__ keys) {
+    __shared__ float4 s_rec[kGenChunk * kGenRecFloat4];
+    __shared__ uint2 s_queue[kGenThreads / 64][kGenQueue];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    uint2* queue = s_queue[tid >> 6];
+    const uint32_t ray0 = blockIdx.x * (uint32_t)kGenBlockRays + (uint32_t)tid;
+    const uint32_t last_ray = (uint32_t)n_rays - 1u;
+
+    // The lane's rays (a ray beyond the end repeats the last one: same key, same value).  Wild rays
+    // take part in the filter arithmetic as zeros and are candidates for every object.
+    F3 ro[kGenRays], rd[kGenRays];
+    uint32_t wild = 0;
+#pragma unroll
+    for (int s = 0; s < kGenRays; ++s) {
+        uint32_t i = ray0 + (uint32_t)s * kGenThreads;
+        if (i > last_ray) i = last_ray;
+        const float4 o4 = rays[2 * (size_t)i], d4 = rays[2 * (size_t)i + 1];
+        const bool w = is_wild(o4, d4);
+        wild |= w ? (1u << s) : 0u;
+        ro[s] = w ? mk3(0.f, 0.f, 0.f) : mk3(o4.x, o4.y, o4.z);
+        rd[s] = w ? mk3(0.f, 0.f, 0.f) : mk3(d4.x, d4.y, d4.z);
+    }
+    const uint32_t wild_sign = wild ? 0x80000000u : 0u;
+    uint32_t queued = 0;                                  // entries waiting in the wave's queue (wave-uniform)
+
+    // The reference arithmetic for `count` queue entries from `from` on, one per lane.
+    auto run_queue = [&](uint32_t from, uint32_t count) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if ((uint32_t)lane < count) {
+            const uint2 e = queue[from + lane];
+            const uint32_t i = e.x, obj = e.y;
+            const float4 g0 = geo[3 * (size_t)obj], g1 = geo[3 * (size_t)obj + 1], g2 = geo[3 * (size_t)obj + 2];
+            const float4 o4 = rays[2 * (size_t)i], d4 = rays[2 * (size_t)i + 1];
+            const F3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+            float t;
+            bool hit;
+            if (g0.w != 0.0f) {
+                hit = tri_exact(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), o, d, t_upper, t_lower, t);
+            } else {
+                bool two;
+                hit = sphere_exact(mk3(g0.x, g0.y, g0.z), g1.x, o, d, t_upper, t_lower, t, two);
+            }
+            if (hit && t > t_lower && t < t_upper)                  // kernel.cl:326,344
+                atomicMin(&keys[i], ((unsigned long long)ordered_bits(t) << 32) | obj);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // Appends (ray of slot s, obj) for the lanes of `mask`; at most 64 entries per call.
+    auto push = [&](uint64_t mask, bool mine, int s, uint32_t obj) {
+        if (mine) {
+            uint32_t i = ray0 + (uint32_t)s * kGenThreads;
+            if (i > last_ray) i = last_ray;
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            queue[queued + before] = make_uint2(i, obj);
+        }
+        queued += (uint32_t)__builtin_popcountll(mask);
+    };
+    auto drain = [&](uint32_t keep) {
+        while (queued > keep) {
+            const uint32_t n = queued < 64u ? queued : 64u;
+            queued -= n;
+            run_queue(queued, n);
+        }
+    };
+
+    // ---- triangles of this slice ----
+    const int t_begin = (int)blockIdx.z * tris_per_slice;
+    const int t_end = t_begin + tris_per_slice < n_tri ? t_begin + tris_per_slice : n_tri;
+    for (int cbase = t_begin; cbase < t_end; cbase += kGenChunk) {
+        const int count = t_end - cbase < kGenChunk ? t_end - cbase : kGenChunk;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kGenRecFloat4; ++k) {
+            const int i = tid + k * kGenThreads;
+            if (i < count * kGenRecFloat4) s_rec[i] = tri_rec[(size_t)cbase * kGenRecFloat4 + i];
+        }
+        __syncthreads();
+        for (int g = 0; g < count; ++g) {
+            const float4 q0 = s_rec[g * kGenRecFloat4 + 0];
+            const float4 q1 = s_rec[g * kGenRecFloat4 + 1];
+            const float4 q2 = s_rec[g * kGenRecFloat4 + 2];
+            const float4 q3 = s_rec[g * kGenRecFloat4 + 3];
+            const F3 a = mk3(q0.x, q0.y, q0.z), n = mk3(q1.x, q1.y, q1.z);
+            const F3 s2 = mk3(q2.x, q2.y, q2.z), ns1 = mk3(q3.x, q3.y, q3.z);
+            // The sign bit of c[s] is set when ray s may hit: all X >= 0 (a hit with det > 0) or
+            // all X <= 2M (det < 0).
+            uint32_t c[kGenRays];
+            uint32_t any = wild_sign;
+#pragma unroll
+            for (int s = 0; s < kGenRays; ++s) {
+                const F3 sol = sub3(a, ro[s]);                         // as tri_intersect forms it
+                const F3 q = cross_fma(rd[s], sol);
+                const float xb = dot_fma(s2, q, q0.w);
+                const float xg = dot_fma(ns1, q, q0.w);
+                const float xd = dot_fma(n, rd[s], q1.w);
+                const float xw = (xd - xb) - xg;
+                float nlo = __builtin_fmaxf(__builtin_fmaxf(-xb, -xg), -xw);
+                float hi = __builtin_fmaxf(__builtin_fmaxf(xb, xg), xw);
+                if (HAS_T) {
+                    const float xt = dot_fma(n, sol, q0.w);
+                    nlo = __builtin_fmaxf(nlo, -xt);
+                    hi = __builtin_fmaxf(hi, xt);
+                }
+                c[s] = __float_as_uint(nlo) | __float_as_uint(hi - q2.w);
+                any |= c[s];
+            }
+            // (the compare's lane mask itself is the vote: no round trip through a VGPR)
+            if (__builtin_amdgcn_sicmp((int32_t)any, 0, 40 /* ICMP_SLT */) == 0) continue;
+            const uint32_t obj = __builtin_amdgcn_readfirstlane(__float_as_uint(q3.w));
+#pragma unroll
+            for (int s = 0; s < kGenRays; ++s) {
+                const bool mine = (int32_t)(c[s] | ((wild >> s) << 31)) < 0;
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(mine);
+                if (mask) push(mask, mine, s, obj);
+            }
+            drain(63u);
+        }
+    }
+
+    // ---- spheres of this slice ----
+    const int s_begin = (int)blockIdx.z * sph_per_slice;
+    const int s_end = s_begin + sph_per_slice < n_sph ? s_begin + sph_per_slice : n_sph;
+    constexpr int kSphChunk = kGenChunk * kGenRecFloat4 / kGenSphFloat4;
+    for (int cbase = s_begin; cbase < s_end; cbase += kSphChunk) {
+        const int count = s_end - cbase < kSphChunk ? s_end - cbase : kSphChunk;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kGenRecFloat4; ++k) {
+            const int i = tid + k * kGenThreads;
+            if (i < count * kGenSphFloat4) s_rec[i] = sph_rec[(size_t)cbase * kGenSphFloat4 + i];
+        }
+        __syncthreads();
+        for (int g = 0; g < count; ++g) {
+            const float4 sp = s_rec[g * kGenSphFloat4];
+            const F3 center = mk3(sp.x, sp.y, sp.z);
+            // circle_intersect gives up only when the discriminant compares below zero
+            // (kernel.cl:256): a NaN discriminant goes on.
+            uint32_t mine_bits = wild;
+#pragma unroll
+            for (int s = 0; s < kGenRays; ++s) {
+                float qa, qb;
+                mine_bits |= !(sphere_disc(center, sp.w, ro[s], rd[s], qa, qb) < 0.0f) ? (1u << s) : 0u;
+            }
+            if (__builtin_amdgcn_ballot_w64(mine_bits != 0) == 0) continue;
+            const uint32_t obj = __builtin_amdgcn_readfirstlane(__float_as_uint(s_rec[g * kGenSphFloat4 + 1].x));
+#pragma unroll
+            for (int s = 0; s < kGenRays; ++s) {
+                const bool mine = (mine_bits >> s) & 1u;
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(mine);
+                if (mask) push(mask, mine, s, obj);
+            }
+            drain(63u);
+        }
+    }
+    drain(0u);
+}
+
+// Decodes the keys: the winner's hit record, with t, location and normal from the reference
+// arithmetic (tri_intersect / circle_intersect, kernel.cl:197-303).
+__global__ void general_finish_kernel(const float4* __restrict__ geo, const float4* __restrict__ rays, int n_rays,
+                                      const unsigned long long* __restrict__ keys, float t_upper, float t_lower,
+                                      HitOut* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rays) return;
-    const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
-    const F3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
-    float temp_max = t_upper;   // kernel.cl:307
-    int best = -1;
-    for (int j = 0; j < n_objects; ++j) {
-        const float4 g0 = geo[3 * (size_t)j], g1 = geo[3 * (size_t)j + 1], g2 = geo[3 * (size_t)j + 2];
-        float t;
-        bool hit;
-        if (g0.w != 0.0f) {
-            hit = tri_exact(mk3(g0.x, g0.y, g0.z), mk3(g1.x, g1.y, g1.z), mk3(g2.x, g2.y, g2.z), o, d,
-                            temp_max, t_lower, t);
-        } else {
-            bool two;
-            hit = sphere_exact(mk3(g0.x, g0.y, g0.z), g1.x, o, d, temp_max, t_lower, t, two);
-        }
-        if (hit && t > t_lower && t < temp_max) { temp_max = t; best = j; }   // kernel.cl:326,344
-    }
+    const unsigned long long key = keys[i];
+    const int best = (key == ~0ull) ? -1 : (int)(uint32_t)key;
     HitOut h;
     h.loc_t = make_float4(0.f, 0.f, 0.f, -1.0f);
     h.n_id = make_float4(0.f, 0.f, 0.f, __int_as_float(best));
     if (best >= 0) {
+        const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
+        const F3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
         const float4 g0 = geo[3 * (size_t)best], g1 = geo[3 * (size_t)best + 1], g2 = geo[3 * (size_t)best + 2];
-        const float t = temp_max;
-        const F3 loc = add3(o, scale3(d, t));
-        F3 n;
+        float t = 0.f;
+        F3 n, loc;
         if (g0.w != 0.0f) {
-            const F3 A = mk3(g0.x, g0.y, g0.z);
-            n = normalize3(cross3(sub3(A, mk3(g1.x, g1.y, g1.z)), sub3(A, mk3(g2.x, g2.y, g2.z))));
+            const F3 A = mk3(g0.x, g0.y, g0.z), B = mk3(g1.x, g1.y, g1.z), C = mk3(g2.x, g2.y, g2.z);
+            (void)tri_exact(A, B, C, o, d, t_upper, t_lower, t);
+            loc = add3(o, scale3(d, t));
+            n = normalize3(cross3(sub3(A, B), sub3(A, C)));
         } else {
             const F3 c = mk3(g0.x, g0.y, g0.z);
-            float a, b;
-            const float disc = sphere_disc(c, g1.x, o, d, a, b);
-            if (disc > 0) n = normalize3(div3(sub3(loc, c), g1.x));
+            bool two = false;
+            (void)sphere_exact(c, g1.x, o, d, t_upper, t_lower, t, two);
+            loc = add3(o, scale3(d, t));
+            if (two) n = normalize3(div3(sub3(loc, c), g1.x));
             else n = normalize3(sub3(loc, c));
         }
         h.loc_t = make_float4(loc.x, loc.y, loc.z, t);
@@ -317,33 +645,116 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
         return mrt_stage_set_error_(ctx, MRT_ERR_INVALID, "bad object array");
     if (n_rays == 0) return MRT_OK;
     static_assert(sizeof(mrt_cl_object) == 144, "object must be 144 bytes");
-    std::vector<float4> geo((size_t)n_objects * 3);
-    for (int j = 0; j < n_objects; ++j) {
+    // One upload for everything the kernels read about the objects: the exact records in the
+    // caller's order, the object indices of the triangles, the sphere records, and six zeroed
+    // words for the ray bounds.  Sections start on 256-byte boundaries.
+    auto align256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    int n_tri = 0;
+    for (int j = 0; j < n_objects; ++j) n_tri += objects[j].is_triangle ? 1 : 0;
+    const int n_sph = n_objects - n_tri;
+    const size_t off_geo = 0;
+    const size_t off_tri = align256(off_geo + (size_t)n_objects * 3 * sizeof(float4));
+    const size_t off_sph = align256(off_tri + (size_t)n_tri * sizeof(uint32_t));
+    const size_t off_bounds = align256(off_sph + (size_t)n_sph * mrt::kGenSphFloat4 * sizeof(float4));
+    const size_t pack_bytes = off_bounds + 256;
+    std::vector<unsigned char> pack(pack_bytes, 0);
+    float4* geo = reinterpret_cast<float4*>(pack.data() + off_geo);
+    uint32_t* tri_objs = reinterpret_cast<uint32_t*>(pack.data() + off_tri);
+    float4* sph_rec = reinterpret_cast<float4*>(pack.data() + off_sph);
+    for (int j = 0, it = 0, is = 0; j < n_objects; ++j) {
         const mrt_cl_object& o = objects[j];
         // kernel.cl:322: is_triangle selects the triangle test, anything else is a sphere.
         if (o.is_triangle) {
             geo[3 * (size_t)j] = make_float4(o.triObj.a.s[0], o.triObj.a.s[1], o.triObj.a.s[2], 1.0f);
             geo[3 * (size_t)j + 1] = make_float4(o.triObj.b.s[0], o.triObj.b.s[1], o.triObj.b.s[2], 0.f);
             geo[3 * (size_t)j + 2] = make_float4(o.triObj.c.s[0], o.triObj.c.s[1], o.triObj.c.s[2], 0.f);
+            tri_objs[it++] = (uint32_t)j;
         } else {
             geo[3 * (size_t)j] = make_float4(o.circleObj.center.s[0], o.circleObj.center.s[1], o.circleObj.center.s[2], 0.0f);
             geo[3 * (size_t)j + 1] = make_float4(o.circleObj.radius, 0.f, 0.f, 0.f);
             geo[3 * (size_t)j + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float idx;
+            const uint32_t ju = (uint32_t)j;
+            std::memcpy(&idx, &ju, 4);
+            sph_rec[(size_t)is * mrt::kGenSphFloat4] = geo[3 * (size_t)j];
+            sph_rec[(size_t)is * mrt::kGenSphFloat4].w = o.circleObj.radius;
+            sph_rec[(size_t)is * mrt::kGenSphFloat4 + 1] = make_float4(idx, 0.f, 0.f, 0.f);
+            ++is;
         }
     }
     hipStream_t stage_stream = (hipStream_t)mrt_ctx_stream_(ctx);
-    DevBuf d_geo, d_rays, d_out;
-    STAGE_BUF(d_geo, 0, geo.size() * sizeof(float4));
+    DevBuf d_pack, d_rays, d_out, d_rec, d_keys;
+    STAGE_BUF(d_pack, 0, pack_bytes);
     STAGE_BUF(d_rays, 1, (size_t)n_rays * 32);
     STAGE_BUF(d_out, 2, (size_t)n_rays * sizeof(mrt::HitOut));
-    if (!geo.empty()) STAGE_COPY(d_geo.p, geo.data(), geo.size() * sizeof(float4), hipMemcpyHostToDevice);
+    STAGE_BUF(d_rec, 3, (size_t)(n_tri ? n_tri : 1) * mrt::kGenRecFloat4 * sizeof(float4));
+    STAGE_BUF(d_keys, 4, (size_t)n_rays * sizeof(unsigned long long));
+    unsigned char* dp = static_cast<unsigned char*>(d_pack.p);
+    const float4* d_geo = reinterpret_cast<const float4*>(dp + off_geo);
+    const uint32_t* d_tri = reinterpret_cast<const uint32_t*>(dp + off_tri);
+    const float4* d_sph = reinterpret_cast<const float4*>(dp + off_sph);
+    uint32_t* d_bounds = reinterpret_cast<uint32_t*>(dp + off_bounds);
+    STAGE_COPY(d_pack.p, pack.data(), pack_bytes, hipMemcpyHostToDevice);
     STAGE_COPY(d_rays.p, rays, (size_t)n_rays * 32, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(mrt::stage_intersect_kernel, grid_for(n_rays), dim3(256), 0, stage_stream, (const float4*)d_geo.p,
-                       n_objects, (const float4*)d_rays.p, n_rays, t_upper_bound, t_lower_bound,
+
+    // The object list in slices (grid layers), so that a call with few rays still fills the GPU.
+    // The GPU holds kResidentBlocks blocks at a time (four per compute unit: four waves per SIMD);
+    // blocks of one launch take about the same time, so the launch is sized to a whole number of
+    // rounds -- about six -- with the last one nearly full, a slice at least 32 triangles.
+    const int ray_blocks = (n_rays + mrt::kGenBlockRays - 1) / mrt::kGenBlockRays;
+    constexpr int kResidentBlocks = 256 * 4;
+    const int max_slices = n_tri / 32 > 1 ? n_tri / 32 : 1;
+    int slices = 1;
+    if (ray_blocks < 6 * kResidentBlocks) {
+        slices = (6 * kResidentBlocks) / ray_blocks;          // rounds down: the last round is not overfull
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+    }
+    static const int forced_slices = [] {                      // tuning aid, read once per process
+        const char* e = std::getenv("MRT_STAGE_SLICES");
+        const long v = e ? std::strtol(e, nullptr, 10) : 0;
+        return v > 0 && v < 65536 ? (int)v : 0;
+    }();
+    if (forced_slices) slices = forced_slices < max_slices ? forced_slices : max_slices;
+    const int tris_per_slice = (n_tri + slices - 1) / slices;
+    const int sph_per_slice = (n_sph + slices - 1) / slices;
+
+    hipEvent_t ev0 = (hipEvent_t)mrt_stage_event_(ctx, 0), ev1 = (hipEvent_t)mrt_stage_event_(ctx, 1);
+    STAGE_TRY(hipEventRecord(ev0, stage_stream));
+    STAGE_TRY(hipMemsetAsync(d_keys.p, 0xFF, (size_t)n_rays * sizeof(unsigned long long), stage_stream));
+    {
+        const int blocks = (n_rays + 1023) / 1024;
+        hipLaunchKernelGGL(mrt::general_ray_bounds, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stage_stream,
+                           (const float4*)d_rays.p, n_rays, d_bounds);
+        STAGE_TRY(hipGetLastError());
+    }
+    if (n_tri) {
+        hipLaunchKernelGGL(mrt::prep_general_records, dim3((n_tri + 255) / 256), dim3(256), 0, stage_stream, d_geo, d_tri,
+                           n_tri, (const uint32_t*)d_bounds, (float4*)d_rec.p);
+        STAGE_TRY(hipGetLastError());
+    }
+    if (n_objects) {
+        const dim3 grid((unsigned)ray_blocks, 1, (unsigned)slices);
+        if (t_lower_bound >= 0.0f)
+            hipLaunchKernelGGL(mrt::general_intersect_kernel<true>, grid, dim3(mrt::kGenThreads), 0, stage_stream,
+                               (const float4*)d_rays.p, n_rays, (const float4*)d_rec.p, n_tri, tris_per_slice, d_sph, n_sph,
+                               sph_per_slice, d_geo, t_upper_bound, t_lower_bound, (unsigned long long*)d_keys.p);
+        else
+            hipLaunchKernelGGL(mrt::general_intersect_kernel<false>, grid, dim3(mrt::kGenThreads), 0, stage_stream,
+                               (const float4*)d_rays.p, n_rays, (const float4*)d_rec.p, n_tri, tris_per_slice, d_sph, n_sph,
+                               sph_per_slice, d_geo, t_upper_bound, t_lower_bound, (unsigned long long*)d_keys.p);
+        STAGE_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(mrt::general_finish_kernel, grid_for(n_rays), dim3(256), 0, stage_stream, d_geo,
+                       (const float4*)d_rays.p, n_rays, (const unsigned long long*)d_keys.p, t_upper_bound, t_lower_bound,
                        (mrt::HitOut*)d_out.p);
     STAGE_TRY(hipGetLastError());
+    STAGE_TRY(hipEventRecord(ev1, stage_stream));
     std::vector<mrt::HitOut> res((size_t)n_rays);
     STAGE_COPY(res.data(), d_out.p, (size_t)n_rays * sizeof(mrt::HitOut), hipMemcpyDeviceToHost);
+    float kernel_ms = 0.f;
+    STAGE_TRY(hipEventElapsedTime(&kernel_ms, ev0, ev1));
+    mrt_stage_set_kernel_ms_(ctx, (double)kernel_ms);
     for (int i = 0; i < n_rays; ++i) {
         const mrt::HitOut& h = res[(size_t)i];
         int id;
@@ -369,6 +780,8 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
     }
     return MRT_OK;
 }
+
+double mrt_stage_last_kernel_ms(const mrt_ctx* ctx) { return ctx ? mrt_stage_get_kernel_ms_(ctx) : 0.0; }
 
 int mrt_stage_flat_shader(mrt_ctx* ctx, const mrt_cl_intersect* xsects, int n, mrt_cl_rgb background,
                           mrt_cl_rgb* out) {

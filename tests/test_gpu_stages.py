@@ -138,3 +138,133 @@ def test_stage_zero_elements_and_errors(gpu_ctx, mrt):
     with pytest.raises(mrt.MrtError):
         mrt.lib().mrt_stage_uv.argtypes  # keep flake quiet
         gpu_ctx._check(mrt.lib().mrt_stage_uv(gpu_ctx._h, None, None, 5, None))
+
+
+def oracle_intersect_threads(oracle, objs, rays, hi, lo, out=None, threads=16):
+    """oracle.stage_intersect over chunks of the rays on host threads (the C call drops the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(rays)
+    res = np.zeros(n, oracle.mrt.CL_DTYPES["intersect"]) if out is None else out
+    ids = np.zeros(n, np.int32)
+    step = max(1, (n + threads - 1) // threads)
+
+    def run(a):
+        b = min(n, a + step)
+        _, i = oracle.stage_intersect(objs, rays[a:b], hi, lo, out=res[a:b])
+        ids[a:b] = i
+
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(run, range(0, n, step)))
+    return res, ids
+
+
+def random_objects(mrt, rng, n_tri, n_sph, span=3.0, tri_size=0.6):
+    """Triangles and spheres interleaved in random order (the reference's object array may hold
+    them in any order: kernel.cl:322 branches per object)."""
+    D = mrt.CL_DTYPES
+    n = n_tri + n_sph
+    objs = np.zeros(n, D["object"])
+    kind = np.zeros(n, bool)
+    kind[rng.permutation(n)[:n_tri]] = True
+    for j in range(n):
+        c = rng.uniform(-span, span, 3).astype(np.float32)
+        if kind[j]:
+            for key in ("a", "b", "c"):
+                objs[key][j, :3] = c + rng.uniform(-tri_size, tri_size, 3).astype(np.float32)
+            objs["tri_color"][j, :3] = rng.uniform(0, 1, 3)
+            objs["tri_shininess"][j] = float(2 ** rng.integers(1, 6))
+            objs["is_triangle"][j] = 1
+        else:
+            objs["center"][j, :3] = c
+            objs["radius"][j] = rng.uniform(0.05, 0.5)
+            objs["sph_color"][j, :3] = rng.uniform(0, 1, 3)
+            objs["sph_shininess"][j] = float(2 ** rng.integers(1, 6))
+            objs["is_circle"][j] = 1
+    return objs
+
+
+def random_rays(mrt, rng, n, span=3.0):
+    """Rays with origins all over the scene and directions all over the sphere, lengths from
+    0.01 to 100: nothing a shared origin or direction could be precomputed from."""
+    rays = np.zeros(n, mrt.CL_DTYPES["ray"])
+    rays["origin"][:, :3] = rng.uniform(-span, span, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays["direction"][:, :3] = d * 10.0 ** rng.uniform(-2, 2, (n, 1))
+    return rays
+
+
+@pytest.mark.parametrize("seed,n_tri,n_sph,n_rays", [(1, 700, 60, 20000), (2, 33, 0, 5000), (3, 0, 40, 3000),
+                                                    (4, 1500, 300, 4097), (5, 1, 1, 1)])
+def test_stage_intersect_arbitrary_rays(gpu_ctx, mrt, oracle, seed, n_tri, n_sph, n_rays):
+    """Every ray with its own origin and direction, objects in mixed order, every t range the
+    loop of kernel.cl:305-379 can be given -- among them negative lower bounds, where hits behind
+    the origin count -- bit for bit against the oracle."""
+    rng = np.random.default_rng(seed)
+    objs = random_objects(mrt, rng, n_tri, n_sph)
+    rays = random_rays(mrt, rng, n_rays)
+    # duplicates of an object further down the array: equal t must go to the lower index
+    if len(objs) > 8:
+        objs[-1] = objs[2]
+        objs[-3] = objs[5]
+    FLT_MAX = float(np.finfo(np.float32).max)
+    for hi, lo in [(FLT_MAX, 0.0), (2.5, 0.0), (FLT_MAX, -4.0), (1.0, -1.0), (np.inf, 0.25), (0.5, 1.0)]:
+        g = gpu_ctx.stage_intersect(objs, rays, hi, lo)
+        o, ids = oracle.stage_intersect(objs, rays, hi, lo)
+        same_records(g, o)
+    assert gpu_ctx.stage_kernel_ms() > 0.0
+
+
+def test_stage_intersect_wild_rays_and_odd_objects(gpu_ctx, mrt, oracle):
+    """Non-finite and huge ray components, rays of zero direction, degenerate and enormous
+    triangles, spheres of zero / negative / NaN radius: whatever the reference arithmetic makes of
+    them (kernel.cl:197-303), the library makes the same."""
+    rng = np.random.default_rng(11)
+    objs = random_objects(mrt, rng, 300, 40)
+    objs["b"][3] = objs["a"][3]                        # two equal vertices
+    objs["c"][4] = objs["a"][4]; objs["b"][4] = objs["a"][4]
+    tri = np.flatnonzero(objs["is_triangle"])
+    sph = np.flatnonzero(objs["is_circle"])
+    objs["a"][tri[10], :3] *= 1e30                     # products overflow
+    objs["b"][tri[11], 0] = np.inf
+    objs["c"][tri[12], 1] = np.nan
+    objs["a"][tri[13], :3] = 1e-30                     # products in the denormal range
+    objs["b"][tri[13], :3] = (2e-30, 1e-30, 1e-30)
+    objs["c"][tri[13], :3] = (1e-30, 2e-30, 1e-30)
+    objs["radius"][sph[0]] = 0.0
+    objs["radius"][sph[1]] = -0.3
+    objs["radius"][sph[2]] = np.nan
+    objs["center"][sph[3], 0] = np.inf
+    rays = random_rays(mrt, rng, 6000)
+    rays["origin"][5, 0] = np.nan
+    rays["direction"][6, 1] = np.nan
+    rays["direction"][7, 2] = np.inf
+    rays["origin"][8, 1] = -np.inf
+    rays["origin"][9, :3] = 1e30
+    rays["direction"][10, :3] = (1e25, -1e25, 3e24)
+    rays["direction"][11, :3] = 0.0
+    rays["direction"][12, :3] = (1e-30, 2e-30, -1e-30)
+    rays["origin"][13, :3] = (3e19, 0.0, 0.0)          # beyond the filter's range, finite
+    rays["direction"][13, :3] = (-1.0, 0.0, 0.0)
+    FLT_MAX = float(np.finfo(np.float32).max)
+    for hi, lo in [(FLT_MAX, 0.0), (np.inf, -np.inf), (FLT_MAX, -1.0), (np.nan, 0.0)]:
+        g = gpu_ctx.stage_intersect(objs, rays, hi, lo)
+        o, _ = oracle.stage_intersect(objs, rays, hi, lo)
+        same_records(g, o)
+
+
+def test_stage_intersect_native_frame(gpu_ctx, mrt, oracle):
+    """The reference's own workload: teatime at 400x400, 160 000 rays x 4034 objects, every record
+    against the oracle; and the device time of the call's kernels."""
+    sc = scene_py.load_scene(SCENES / "teatime.json")
+    pos, vp, cam, objs, lights, phong = make_inputs(mrt, sc, 400)
+    uv = gpu_ctx.stage_uv(pos, vp)
+    rays = gpu_ctx.stage_viewrays(cam, uv, sc.struct.focal)
+    FLT_MAX = float(np.finfo(np.float32).max)
+    g = gpu_ctx.stage_intersect(objs, rays, FLT_MAX, 0.0)
+    ms = gpu_ctx.stage_kernel_ms()
+    o, ids = oracle_intersect_threads(oracle, objs, rays, FLT_MAX, 0.0)
+    assert (ids >= 0).sum() > 10000
+    same_records(g, o)
+    print(f"stage_intersect 160000 x {len(objs)}: kernels {ms:.3f} ms, {160000 * len(objs) / ms * 1e-9:.2f}e12 tests/s")
+    assert ms < 5.0

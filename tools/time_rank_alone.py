@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""One rank's share of a strong-scaled frame, alone on the GPU (GPU box only).
+
+The compute side of the multi-GPU scaling curve can be bounded on one GPU: render the interleaved
+64-row bands that rank r of `world` owns, with nothing else on the device, and compare with the
+whole frame on the same device.  eff = T(whole frame) / (world * T(rank alone)) is the strong-scaling
+efficiency N GPUs would reach if the gather cost nothing; 1 / eff - 1 is what cutting the frame into
+bands costs by itself (fewer waves per launch, a shading pass of its own, the lane shape chosen on
+the rank's rows).
+
+usage: time_rank_alone.py [soup|teatime8k|both] [--json PATH] [--reps N]
+"""
+import argparse
+import json
+import statistics
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
+import torch  # noqa: E402  (one HIP runtime for the process)
+import mrt_pkg  # noqa: E402
+import mkscene  # noqa: E402
+
+BAND = 64
+
+
+def rank_alone(mrt, scene, world, rank, reps, flags=0):
+    """Median device time (HIP events inside the library: trace + shade) and wall time per frame of
+    `reps` frames enqueued back to back, for rank `rank` of `world`."""
+    st = scene.struct
+    rows = mrt.band_rows(st.yres, BAND, rank, world)
+    buf = torch.empty(rows * st.xres, dtype=torch.int32, device="cuda:0")
+    ctx = mrt.Context(device=0, flags=flags)
+    try:
+        ctx.set_scene(scene)
+        for _ in range(2):
+            ctx.render_bands_device(BAND, rank, world, buf.data_ptr(), buf.numel() * 4)
+        torch.cuda.synchronize()
+        ev = []
+        for _ in range(reps):
+            s = ctx.render_bands_device(BAND, rank, world, buf.data_ptr(), buf.numel() * 4, timed=True)
+            ev.append((s.trace_ms + s.shade_ms, s.trace_ms, s.shade_ms, s.kernel, s.prim_slices))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.render_bands_device(BAND, rank, world, buf.data_ptr(), buf.numel() * 4)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps * 1e3
+    finally:
+        ctx.close()
+    med = statistics.median(e[0] for e in ev)
+    return {"rows": rows, "kernel_ms": med, "trace_ms": statistics.median(e[1] for e in ev),
+            "shade_ms": statistics.median(e[2] for e in ev), "back_to_back_ms": wall,
+            "kernel": int(ev[0][3]), "slices": int(ev[0][4])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="?", default="both")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--flags", type=lambda s: int(s, 0), default=0)
+    args = ap.parse_args()
+    mrt = mrt_pkg.load()
+    frames = []
+    if args.which in ("soup", "both"):
+        frames.append(("soup16k", mkscene.soup(16384, 16384)))
+    if args.which in ("teatime8k", "both"):
+        frames.append(("teatime8k", mkscene.teatime(7680, 4320)))
+    if args.which == "teatime4k":
+        frames.append(("teatime4k", mkscene.teatime(3840, 2160)))
+    res = {}
+    for name, text in frames:
+        scene = mrt.LoadedScene(text=text).copy()
+        full = rank_alone(mrt, scene, 1, 0, args.reps, args.flags)
+        res[name] = {"full_frame": full}
+        print(f"{name} whole frame: {full}", flush=True)
+        for world in (2, 4, 8):
+            for rank in sorted({0, world - 1}):
+                r = rank_alone(mrt, scene, world, rank, args.reps, args.flags)
+                r["compute_eff_kernel"] = full["kernel_ms"] / (world * r["kernel_ms"])
+                r["compute_eff_back_to_back"] = full["back_to_back_ms"] / (world * r["back_to_back_ms"])
+                res[name][f"w{world}_r{rank}"] = r
+                print(f"{name} world {world} rank {rank}: {r}", flush=True)
+    if args.json:
+        Path(args.json).write_text(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -28,9 +28,21 @@ for rep in range(3):
     uv = ctx.stage_uv(pos, vp); t.append(time.perf_counter())
     rays = ctx.stage_viewrays(cam, uv, focal); t.append(time.perf_counter())
     xs = ctx.stage_intersect(objs, rays, FLT_MAX, 0.0); t.append(time.perf_counter())
+    kms = ctx.stage_kernel_ms()
     col = ctx.stage_phong(xs, phong, bg, cam, lights); t.append(time.perf_counter())
     ms = [(b - a) * 1e3 for a, b in zip(t, t[1:])]
-    print(f"stages {name} 400x400: uv {ms[0]:.2f} rays {ms[1]:.2f} intersect {ms[2]:.2f} phong {ms[3]:.2f} total {sum(ms):.2f} ms", flush=True)
+    print(f"stages {name} 400x400: uv {ms[0]:.2f} rays {ms[1]:.2f} intersect {ms[2]:.2f} phong {ms[3]:.2f} total {sum(ms):.2f} ms; intersect kernels {kms:.3f} ms", flush=True)
+# the device side of stage_intersect alone, warm: every (ray, object) pair in kms milliseconds
+import os  # noqa: E402
+t_lower = float(os.environ.get("MRT_TIME_STAGES_T_LOWER", "0"))
+kk = []
+for rep in range(30):
+    ctx.stage_intersect(objs, rays, FLT_MAX, t_lower)
+    kk.append(ctx.stage_kernel_ms())
+kk.sort()
+pairs = len(rays) * len(objs)
+print(f"stage_intersect kernels {name}: {len(rays)} rays x {len(objs)} objects: best {kk[0]:.3f} ms, median {kk[len(kk) // 2]:.3f} ms "
+      f"= {pairs / kk[len(kk) // 2] * 1e-9:.3f}e12 tests/s", flush=True)
 ctx.set_scene(sc)
 for rep in range(3):
     t0 = time.perf_counter()
