@@ -75,16 +75,21 @@ __global__ void stage_rays_kernel(CamK c, const float2* __restrict__ uv, int n, 
 //
 // Triangles.  tri_intersect (kernel.cl:197-235) solves by Cramer's rule: det,
 // Nb, Ng, Nt, then beta = Nb/det, gamma = Ng/det, t = Nt/det and the range
-// tests.  With s1 = a - b, s2 = a - c, n = s1 x s2 (per triangle), sol = a - o
-// and q = d x sol (per pair):
-//     det = d . n     Nt = sol . n     Nb = s2 . q     Ng = -s1 . q
-// One vector subtraction, one cross product and four dot products per pair,
-// evaluated with fused multiply-adds -- a conservative filter, never the
-// decision: a hit needs Nb, Ng and W = det - Nb - Ng (and Nt, when t_lower >= 0)
+// tests, the determinants being triple products of s1 = a - b, s2 = a - c,
+// sol = a - o and d.  Expanding sol and using the moment m = d x o of the ray
+// (per ray) and n = s1 x s2, A1 = a x s1, A2 = a x s2, k = a . n (per triangle):
+//     det = d . n     Nt = k - o . n     Nb = d . A2 - s2 . m     Ng = s1 . m - d . A1
+// -- the four determinants of a general ray as six dot products of the
+// ray's (d, m, o) with per-triangle vectors, 18 fused multiply-adds per pair
+// and neither a subtraction nor a cross product.  It is a conservative filter,
+// never the decision: a hit needs Nb, Ng and W = det - Nb - Ng (and Nt, when t_lower >= 0)
 // to have the sign of det, and since det = Nb + Ng + W that is "all of one
-// sign".  The fused values differ from the reference's unfused ones by at most
-// 10 u P (u = 2^-24, P the sum of the absolute values of the six products of
-// the determinant); prep_general_records bounds P per triangle over all rays
+// sign".  The fused values differ from the reference's unfused ones by less than
+// 16 u P (u = 2^-24, P the sum of the absolute values of the six products of
+// the determinant with |a| + |o| standing for |sol|: expanding a - o gives up
+// the cancellation the reference's subtraction enjoys, so a scene far from the
+// origin passes more pairs on to the reference arithmetic, never fewer than it
+// must); prep_general_records bounds P per triangle over all rays
 // of the call (general_ray_bounds), takes M = 32 u (sum of the four P) plus the
 // band that keeps a quotient which would round to -0, and the kernel starts
 // every fma chain at +M: X = value + M.  A pair goes on to the reference
@@ -102,8 +107,8 @@ struct HitOut { float4 loc_t; float4 n_id; };
 constexpr int kGenRays = 8;              // rays per lane
 constexpr int kGenThreads = 256;
 constexpr int kGenBlockRays = kGenThreads * kGenRays;
-constexpr int kGenChunk = 256;           // triangle records per LDS chunk (4 float4 each: 16 KiB)
-constexpr int kGenRecFloat4 = 4;
+constexpr int kGenChunk = 256;           // triangle records per LDS chunk (5 float4 each: 20 KiB)
+constexpr int kGenRecFloat4 = 5;
 constexpr int kGenSphFloat4 = 2;         // (cx, cy, cz, r) (object index, -, -, -)
 constexpr int kGenQueue = 64 + kGenRays * 64;   // (ray, object) pairs awaiting the reference arithmetic, per wave
 constexpr float kWildLimit = 0x1p60f;    // rays with a component at or beyond this (or NaN) are "wild"
@@ -173,8 +178,8 @@ __device__ __forceinline__ float round_up_to_float(double x) {
 }
 }  // namespace
 
-// Filter records of general_intersect_kernel, four float4 per triangle, in list order:
-//   (a | M) (n | 3M) (s2 | 2M) (-s1 | object index)
+// Filter records of general_intersect_kernel, five float4 per triangle, in list order:
+//   (A2 | M) (-A1 | 3M) (-s2 | 2M) (s1 | object index) (n | k + M)
 __global__ void prep_general_records(const float4* __restrict__ geo, const uint32_t* __restrict__ tri_objs,
                                      int n_tri, const uint32_t* __restrict__ bounds, float4* __restrict__ rec) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,7 +190,10 @@ __global__ void prep_general_records(const float4* __restrict__ geo, const uint3
     const F3 s1 = sub3(a, mk3(vb.x, vb.y, vb.z));            // kernel.cl:204-205, as the reference rounds them
     const F3 s2 = sub3(a, mk3(vc.x, vc.y, vc.z));
     const F3 n = cross_fma(s1, s2);
-    // magnitudes, with room for the rounding of a - o
+    const F3 a1 = cross_fma(a, s1);
+    const F3 a2 = cross_fma(a, s2);
+    const double kt = (double)a.x * (double)n.x + (double)a.y * (double)n.y + (double)a.z * (double)n.z;
+    // magnitudes, with room for the roundings of d x o and of the sums
     const double ox = 1.01 * (double)__uint_as_float(bounds[0]), oy = 1.01 * (double)__uint_as_float(bounds[1]),
                  oz = 1.01 * (double)__uint_as_float(bounds[2]);
     const double dx = 1.01 * (double)__uint_as_float(bounds[3]), dy = 1.01 * (double)__uint_as_float(bounds[4]),
@@ -200,28 +208,31 @@ __global__ void prep_general_records(const float4* __restrict__ geo, const uint3
     const double big = fmax(fmax(fmax(a1x, a1y), fmax(a1z, a2x)), fmax(fmax(a2y, a2z), fmax(fmax(sx, sy), fmax(sz, fmax(dx, fmax(dy, dz))))));
     // |quotient| < 2^-149 rounds to -0, which passes the reference's "< 0"; products in the
     // denormal range are off by 2^-150 absolutely, scaled by the factor they meet next
-    const double band = p_det * 0x1p-100 + 64.0 * 0x1p-149 * (1.0 + big);
+    const double band = p_det * 0x1p-100 + 64.0 * 0x1p-149 * (1.0 + big * (1.0 + big));
     const double p_all = p_det + p_b + p_g + p_t;
     const double margin = (32.0 / 16777216.0) * p_all + band;
-    float4 r0, r1, r2, r3;
-    if (p_all < 1e36 && margin < 1e36) {                      // false for NaN too
+    float4 r0, r1, r2, r3, r4;
+    if (p_all < 1e36 && margin < 1e36 && fabs(kt) < 1e36) {   // false for NaN too
         const float m = round_up_to_float(margin);
-        r0 = make_float4(a.x, a.y, a.z, m);
-        r1 = make_float4(n.x, n.y, n.z, round_up_to_float(3.0 * (double)m));
-        r2 = make_float4(s2.x, s2.y, s2.z, 2.0f * m);
-        r3 = make_float4(-s1.x, -s1.y, -s1.z, 0.f);
+        r0 = make_float4(a2.x, a2.y, a2.z, m);
+        r1 = make_float4(-a1.x, -a1.y, -a1.z, round_up_to_float(3.0 * (double)m));
+        r2 = make_float4(-s2.x, -s2.y, -s2.z, 2.0f * m);
+        r3 = make_float4(s1.x, s1.y, s1.z, 0.f);
+        r4 = make_float4(n.x, n.y, n.z, (float)(kt + (double)m));
     } else {
         // The margin cannot be bounded: a record every ray passes (all products zero: X = M = 1).
         r0 = make_float4(0.f, 0.f, 0.f, 1.0f);
         r1 = make_float4(0.f, 0.f, 0.f, 3.0f);
         r2 = make_float4(0.f, 0.f, 0.f, 2.0f);
         r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        r4 = make_float4(0.f, 0.f, 0.f, 1.0f);
     }
     r3.w = __uint_as_float(obj);
     rec[(size_t)k * kGenRecFloat4 + 0] = r0;
     rec[(size_t)k * kGenRecFloat4 + 1] = r1;
     rec[(size_t)k * kGenRecFloat4 + 2] = r2;
     rec[(size_t)k * kGenRecFloat4 + 3] = r3;
+    rec[(size_t)k * kGenRecFloat4 + 4] = r4;
 }
 
 // HAS_T: t_lower >= 0, so an accepted t is positive and Nt takes part in the sign test.
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
 
     // The lane's rays (a ray beyond the end repeats the last one: same key, same value).  Wild rays
     // take part in the filter arithmetic as zeros and are candidates for every object.
-    F3 ro[kGenRays], rd[kGenRays];
+    F3 rno[kGenRays], rd[kGenRays], rm[kGenRays];           // -origin, direction, moment d x o
     uint32_t wild = 0;
 #pragma unroll
     for (int s = 0; s < kGenRays; ++s) {
@@ -255,8 +266,10 @@ __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
         const float4 o4 = rays[2 * (size_t)i], d4 = rays[2 * (size_t)i + 1];
         const bool w = is_wild(o4, d4);
         wild |= w ? (1u << s) : 0u;
-        ro[s] = w ? mk3(0.f, 0.f, 0.f) : mk3(o4.x, o4.y, o4.z);
+        const F3 o = w ? mk3(0.f, 0.f, 0.f) : mk3(o4.x, o4.y, o4.z);
         rd[s] = w ? mk3(0.f, 0.f, 0.f) : mk3(d4.x, d4.y, d4.z);
+        rm[s] = cross_fma(rd[s], o);
+        rno[s] = mk3(-o.x, -o.y, -o.z);
     }
     const uint32_t wild_sign = wild ? 0x80000000u : 0u;
     uint32_t queued = 0;                                  // entries waiting in the wave's queue (wave-uniform)
@@ -320,24 +333,23 @@ __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
             const float4 q1 = s_rec[g * kGenRecFloat4 + 1];
             const float4 q2 = s_rec[g * kGenRecFloat4 + 2];
             const float4 q3 = s_rec[g * kGenRecFloat4 + 3];
-            const F3 a = mk3(q0.x, q0.y, q0.z), n = mk3(q1.x, q1.y, q1.z);
-            const F3 s2 = mk3(q2.x, q2.y, q2.z), ns1 = mk3(q3.x, q3.y, q3.z);
+            const float4 q4 = s_rec[g * kGenRecFloat4 + 4];
+            const F3 a2 = mk3(q0.x, q0.y, q0.z), na1 = mk3(q1.x, q1.y, q1.z), ns2 = mk3(q2.x, q2.y, q2.z);
+            const F3 s1 = mk3(q3.x, q3.y, q3.z), n = mk3(q4.x, q4.y, q4.z);
             // The sign bit of c[s] is set when ray s may hit: all X >= 0 (a hit with det > 0) or
             // all X <= 2M (det < 0).
             uint32_t c[kGenRays];
             uint32_t any = wild_sign;
 #pragma unroll
             for (int s = 0; s < kGenRays; ++s) {
-                const F3 sol = sub3(a, ro[s]);                         // as tri_intersect forms it
-                const F3 q = cross_fma(rd[s], sol);
-                const float xb = dot_fma(s2, q, q0.w);
-                const float xg = dot_fma(ns1, q, q0.w);
+                const float xb = dot_fma(ns2, rm[s], dot_fma(a2, rd[s], q0.w));
+                const float xg = dot_fma(s1, rm[s], dot_fma(na1, rd[s], q0.w));
                 const float xd = dot_fma(n, rd[s], q1.w);
                 const float xw = (xd - xb) - xg;
                 float nlo = __builtin_fmaxf(__builtin_fmaxf(-xb, -xg), -xw);
                 float hi = __builtin_fmaxf(__builtin_fmaxf(xb, xg), xw);
                 if (HAS_T) {
-                    const float xt = dot_fma(n, sol, q0.w);
+                    const float xt = dot_fma(n, rno[s], q4.w);
                     nlo = __builtin_fmaxf(nlo, -xt);
                     hi = __builtin_fmaxf(hi, xt);
                 }
@@ -379,7 +391,8 @@ __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
 #pragma unroll
             for (int s = 0; s < kGenRays; ++s) {
                 float qa, qb;
-                mine_bits |= !(sphere_disc(center, sp.w, ro[s], rd[s], qa, qb) < 0.0f) ? (1u << s) : 0u;
+                const F3 o = mk3(-rno[s].x, -rno[s].y, -rno[s].z);         // exact: negation twice
+                mine_bits |= !(sphere_disc(center, sp.w, o, rd[s], qa, qb) < 0.0f) ? (1u << s) : 0u;
             }
             if (__builtin_amdgcn_ballot_w64(mine_bits != 0) == 0) continue;
             const uint32_t obj = __builtin_amdgcn_readfirstlane(__float_as_uint(s_rec[g * kGenSphFloat4 + 1].x));

@@ -268,3 +268,41 @@ def test_stage_intersect_native_frame(gpu_ctx, mrt, oracle):
     same_records(g, o)
     print(f"stage_intersect 160000 x {len(objs)}: kernels {ms:.3f} ms, {160000 * len(objs) / ms * 1e-9:.2f}e12 tests/s")
     assert ms < 5.0
+
+
+@pytest.mark.parametrize("kind", ["generic", "needle", "edge_on", "subpixel", "huge", "behind", "far", "tiny",
+                                  "micro", "denormal", "giant"])
+def test_stage_intersect_fuzz_families(gpu_ctx, mrt, oracle, kind):
+    """The scene families that stress the error margins of the fused kernels (needles, slivers
+    seen edge-on, primitives around the eye, coordinates at 1e-13 ... 1e11, scenes 3e4 units from
+    the origin), through mrt_stage_intersect: the camera's own rays, and rays between random points
+    of the scene, against the oracle bit for bit."""
+    import zlib
+    from test_gpu_prefilter_fuzz import _scene
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) + 7)
+    FLT_MAX = float(np.finfo(np.float32).max)
+    hits = 0
+    for it in range(12):
+        proj = mrt.PROJ_PERSP if it % 2 == 0 else mrt.PROJ_ORTHO
+        sc = _scene(mrt, rng, kind, proj)
+        st = sc.struct
+        side = 64
+        pos, vp, cam, objs, lights, phong = make_inputs(mrt, sc, side)
+        uv = oracle.stage_uv(pos, vp)
+        rays = oracle.stage_viewrays(cam, uv, None if proj == mrt.PROJ_ORTHO else st.focal)
+        # rays from one random vertex towards another, scaled by anything from 0.01 to 100
+        tri = sc.tri.T.reshape(-1, 3, 3)
+        n_extra = 3000
+        a = tri[rng.integers(0, len(tri), n_extra), rng.integers(0, 3, n_extra)]
+        b = tri[rng.integers(0, len(tri), n_extra), rng.integers(0, 3, n_extra)]
+        extra = np.zeros(n_extra, rays.dtype)
+        jitter = rng.normal(size=(n_extra, 3)) * np.abs(b - a).max() * 0.05
+        extra["origin"][:, :3] = a + jitter
+        extra["direction"][:, :3] = (b - a) * 10.0 ** rng.uniform(-2, 2, (n_extra, 1))
+        allrays = np.concatenate([rays, extra])
+        for hi, lo in ((FLT_MAX, 0.0), (FLT_MAX, -FLT_MAX)):
+            g = gpu_ctx.stage_intersect(objs, allrays, hi, lo)
+            o, ids = oracle.stage_intersect(objs, allrays, hi, lo)
+            same_records(g, o)
+            hits += int((ids >= 0).sum())
+    assert hits > 0
