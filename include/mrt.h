@@ -159,7 +159,11 @@ typedef struct mrt_ctx mrt_ctx;
 
 /* Create / destroy a context bound to one GPU.  Replaces initCL()
  * (CLHelpers.hpp:17-74): no program build at run time, kernels are
- * precompiled for gfx950 into the library. */
+ * precompiled for gfx950 into the library.
+ * Environment, read once by mrt_create: MRT_FORCE_SLICES=<1..65536> fixes the
+ * number of slices / layers the primitive list of this context's frames is cut
+ * into instead of the automatic choice (a tuning aid: same pixels, other
+ * timing; anything else in the variable is ignored). */
 int mrt_create(const mrt_config *cfg, mrt_ctx **out);
 void mrt_destroy(mrt_ctx *ctx);
 
@@ -193,6 +197,11 @@ typedef struct mrt_camera {
  * reference has no equivalent: it re-creates context, program and buffers in
  * every stage call (CLHelpers.hpp:79,119,155,196,242,281). */
 int mrt_set_camera(mrt_ctx *ctx, const mrt_camera *camera);
+
+/* Returns when everything this ctx has enqueued so far is over: the record
+ * kernels of mrt_set_camera and the frames, on whatever stream they were put.
+ * What queue.finish() is to the reference's stage helpers (CLHelpers.hpp:111). */
+int mrt_synchronize(mrt_ctx *ctx);
 
 /* Render the whole frame into host memory: xres*yres RGBA8, row-major, pixel
  * (x, y) at 4*(y*xres + x), A = 255.  Bytes are unsigned(x * 255.0f) of the
@@ -245,11 +254,21 @@ int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uin
  * its layers in the key plane, then runs as one layer instead).  Every call on
  * one GPU, from whatever ctx, shares that GPU's array: two such frames in
  * flight at once on one GPU race; enqueue them on one stream or synchronise
- * between them.  Not allocating is all it promises: replaying a call from a
- * captured HIP graph is NOT supported -- the one attempt made (a call captured
- * with torch.cuda.graph and replayed) ended in a GPU memory fault whose cause
- * was not found, and the per-frame state the call keeps on the host (which
- * buffers are clean, the pending per-view records) is not part of a graph.
+ * between them.
+ * HIP graph capture: a call on a stream that is capturing (hipStreamBeginCapture)
+ * records this frame -- the view and scene current at that moment, with the
+ * device addresses of the scene, of its per-view records and of dev_out, and a
+ * clearing of the part of the fixed array the frame uses -- and the graph can
+ * be replayed any number of times.  Nothing of the ctx may be pending on another
+ * stream when the capture begins (mrt_synchronize after the last mrt_set_camera;
+ * MRT_ERR_INVALID otherwise, the capture stays valid): a capturing stream cannot
+ * wait for work outside its graph.  The call records none of the ctx's events,
+ * so mrt_set_camera, mrt_set_scene and
+ * frames on other streams are NOT ordered behind replays by the library: the
+ * caller synchronises between a replay and any of them.  Capture again after
+ * mrt_set_camera (the view is part of the recorded kernel arguments) and after
+ * mrt_set_scene (a scene of other counts moves the buffers).  The allocating
+ * entry points refuse a capturing stream with MRT_ERR_INVALID.
  * No counterpart in the reference, which allocates in every stage call
  * (CLHelpers.hpp:93-104). */
 #define MRT_NOALLOC_MAX_KEYS (8u * 1024u * 1024u)

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "mrt_bands_to_image", "mrt_scene_load_file", "mrt_scene_load_text", "mrt_scene_view",
     "mrt_scene_info_view", "mrt_scene_free", "mrt_write_png_rgb", "mrt_stage_uv",
     "mrt_stage_ortho_viewrays", "mrt_stage_persp_viewrays", "mrt_stage_intersect",
-    "mrt_stage_flat_shader", "mrt_stage_phong_shader", "mrt_stage_last_kernel_ms", "mrt_host_alloc", "mrt_host_free",
+    "mrt_stage_flat_shader", "mrt_stage_phong_shader", "mrt_stage_last_kernel_ms", "mrt_synchronize", "mrt_host_alloc", "mrt_host_free",
     "mrt_render_bands_device_noalloc",
     "mrt_multi_create", "mrt_multi_destroy", "mrt_multi_last_error", "mrt_multi_world", "mrt_multi_gather",
     "mrt_multi_note", "mrt_multi_set_scene", "mrt_multi_set_camera", "mrt_multi_render_rgba8",
@@ -213,6 +213,9 @@ def lib():
     L.mrt_last_error.restype = C.c_char_p
     L.mrt_set_scene.argtypes = [vp, C.POINTER(SceneStruct)]
     L.mrt_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
+    L.mrt_synchronize.argtypes = [vp]
+    L.mrt_set_slices_override_.argtypes = [vp, C.c_uint32]
+    L.mrt_set_slices_override_.restype = None
     L.mrt_render_rgba8.argtypes = [vp, vp, C.POINTER(Stats)]
     L.mrt_render_debug.argtypes = [vp, vp, vp, vp, C.POINTER(Stats)]
     L.mrt_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
@@ -424,6 +427,15 @@ class Context:
             setattr(cam, name, getattr(st, name))
         self._check(lib().mrt_set_camera(self._h, C.byref(cam)))
         self.xres, self.yres = st.xres, st.yres
+
+    def synchronize(self):
+        """Waits for everything the context has enqueued (record kernels, frames)."""
+        self._check(lib().mrt_synchronize(self._h))
+
+    def force_slices(self, n):
+        """Tuning / test aid (not part of the public ABI): cut the primitive list of this context's
+        frames into n slices or layers; 0 = the library's automatic choice."""
+        lib().mrt_set_slices_override_(self._h, int(n))
 
     def render(self, want_ids=False, out=None):
         """Returns (rgba[y, x, 4] uint8, stats) or (rgba, ids, t, stats).  out: an RGBA8 array to

@@ -296,6 +296,7 @@ struct mrt_accel {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build begin/end, frame begin/end
     hipEvent_t grid_ready = nullptr, frame_done = nullptr;
     bool frame_pending = false;
+    hipStream_t last_stream = nullptr;       // the stream of the last GRID frame (frame_done is behind it)
     // frame buffers of the grid method (grown on demand)
     uint32_t* d_out = nullptr;
     size_t out_elems = 0;
@@ -522,6 +523,9 @@ int launch_grid_frame(mrt_accel* a, uint32_t band_rows, uint32_t rank, uint32_t 
         }
         p.fuse_shade = (p.xres % 4 == 0 && ((uintptr_t)dev_out & 15u) == 0) ? 2u : 1u;
         if (stream != (hipStream_t)mrt_ctx_stream_(a->base)) AHIP_TRY(a, hipStreamWaitEvent(stream, a->grid_ready, 0));
+        // Frames of one handle share the counter and the (t, id) planes, and frame_done only
+        // remembers the last one: a frame on another stream runs behind the one before it.
+        if (a->frame_pending && stream != a->last_stream) AHIP_TRY(a, hipStreamWaitEvent(stream, a->frame_done, 0));
         if (p.exact_counter) AHIP_TRY(a, hipMemsetAsync(p.exact_counter, 0, sizeof(unsigned long long), stream));
         const dim3 grid(pitch / mrt::kBlockTileX, prow / mrt::kBlockTileY), block(mrt::kBlockThreads);
         if (mrt_ctx_projection_(a->base) == MRT_PROJ_PERSP)
@@ -533,6 +537,7 @@ int launch_grid_frame(mrt_accel* a, uint32_t band_rows, uint32_t rank, uint32_t 
         AHIP_TRY(a, hipGetLastError());
         AHIP_TRY(a, hipEventRecord(a->frame_done, stream));
         a->frame_pending = true;
+        a->last_stream = stream;
     }
     if (timed) AHIP_TRY(a, hipEventRecord(a->ev[3], stream));
     return MRT_OK;

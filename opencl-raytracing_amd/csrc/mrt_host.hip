@@ -101,6 +101,7 @@ struct mrt_ctx {
     void* d_tri_circle = nullptr;
     size_t cap_sph_filter = 0, cap_tri_filter = 0, cap_tri_circle = 0;
     void* d_tri_exact = nullptr;
+    size_t cap_tri_exact = 0, cap_sph = 0, cap_sph_mat = 0, cap_mats = 0, cap_lights = 0;
     // MRT_FLAG_FULL_TEST only: per-view records of full_trace_kernel, grouped by hit sign, the
     // triangle each record belongs to, and the two group sizes
     void* d_full_rec = nullptr;
@@ -139,6 +140,9 @@ struct mrt_ctx {
     hipEvent_t frame_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool frame_pending = false;
+    // Tuning override of the automatic slice / layer count (0 = automatic): MRT_FORCE_SLICES in the
+    // environment when the ctx is created, or mrt_set_slices_override_.
+    uint32_t force_slices = 0;
 };
 
 namespace {
@@ -182,11 +186,18 @@ void free_dev(void*& p) {
     if (p) { (void)hipFree(p); p = nullptr; }
 }
 
+// Copies `src` into the device buffer `dst` of `cap` bytes, which is replaced only when the size
+// changes: a scene of the same shape keeps its device addresses (a captured HIP graph of a frame
+// holds them).
 template <typename T>
-int upload(mrt_ctx* ctx, void*& dst, const std::vector<T>& src) {
-    free_dev(dst);
+int upload(mrt_ctx* ctx, void*& dst, size_t& cap, const std::vector<T>& src) {
     size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
-    HIP_TRY(ctx, hipMalloc(&dst, bytes));
+    if (!dst || cap != bytes) {
+        free_dev(dst);
+        cap = 0;
+        HIP_TRY(ctx, hipMalloc(&dst, bytes));
+        cap = bytes;
+    }
     if (!src.empty())
         HIP_TRY(ctx, hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return MRT_OK;
@@ -263,6 +274,16 @@ int ensure_out(mrt_ctx* ctx, size_t elems) {
 
 inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
+// Whether `stream` is recording into a HIP graph (hipStreamBeginCapture) instead of executing.
+bool stream_is_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &status) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return status == hipStreamCaptureStatusActive;
+}
+
 // Where a frame's working planes come from: the ctx's own buffers, grown on demand, or
 // planes the caller brings (no allocation; t / id may then be absent).
 struct FramePlanes {
@@ -276,6 +297,13 @@ struct FramePlanes {
 // on `stream`.
 int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world, uint32_t* dev_out,
                  hipStream_t stream, bool timed, const FramePlanes& planes) {
+    // A frame recorded into a HIP graph: only the entry point that allocates nothing and keeps no
+    // per-frame state on the host can be replayed (the others grow buffers, skip the clearing of
+    // planes they know to be clean, and time with events of the ctx).
+    const bool capturing = stream_is_capturing(stream);
+    if (capturing && (planes.own || timed))
+        return fail(ctx, MRT_ERR_INVALID,
+                    "the stream is capturing a HIP graph: only mrt_render_bands_device_noalloc can be captured");
     RenderParams p = ctx->params;
     p.band_rows = band_rows;
     p.rank = rank;
@@ -325,14 +353,13 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
 
     // full_trace_kernel in layers (see the kernel): a frame of few waves -- a 4K frame is four
     // rounds of them, which start and finish in step -- is cut into about 64 K waves, each layer
-    // a share of the record chunks; the layers meet in the key plane.  MRT_FORCE_SLICES overrides.
+    // a share of the record chunks; the layers meet in the key plane.  ctx->force_slices overrides.
     const dim3 fgrid2(pitch / mrt::kBlockTileX, prow / mrt::kFullBlockH);      // blocks of 64 x 32 pixels
     uint32_t full_layers = 1;
     if (full) {
         const uint32_t waves = fgrid2.x * fgrid2.y * (mrt::kBlockThreads / 64);
         const uint32_t chunks = p.n_tri_padded / mrt::kChunkTris;
-        const char* force = std::getenv("MRT_FORCE_SLICES");          // tuning aid
-        full_layers = force ? (uint32_t)std::atoi(force) : (65536u + waves - 1) / waves;
+        full_layers = ctx->force_slices ? ctx->force_slices : (65536u + waves - 1) / waves;
         if (full_layers > chunks) full_layers = chunks;
         if (full_layers < 1) full_layers = 1;
         if (!planes.own && plane_elems > planes.key_capacity) full_layers = 1;    // no room for keys: one layer needs none
@@ -363,6 +390,13 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         d_id = ctx->d_id;
     }
     // The planes are shared by all frames of this ctx: a frame on another stream waits for the last one.
+    // A capturing stream must not wait on an event recorded outside its graph (the wait would be
+    // refused, or draw the other stream into the capture), nor may the host wait for one while
+    // it captures: whatever the frame depends on must be over before the capture begins.
+    if (capturing && ((ctx->frame_pending && stream != ctx->last_stream) || (ctx->records_pending && stream != ctx->stream)))
+        return fail(ctx, MRT_ERR_INVALID,
+                    "work of this context is still pending on another stream (mrt_set_camera, or a frame): "
+                    "call mrt_synchronize before capturing");
     if (ctx->frame_pending && stream != ctx->last_stream)
         HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->frame_done, 0));
     // The per-view records are built on the ctx's own stream.
@@ -391,13 +425,12 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         static_assert(kMinSliceTris % mrt::kGroupCircle == 0 && mrt::kChunkTris % kMinSliceTris == 0, "slices are whole circle groups");
         const uint32_t waves = tgrid.x * tgrid.y * (mrt::kBlockThreads / 64);
         const uint32_t units = p.n_tri_padded / kMinSliceTris;
-        const char* force = std::getenv("MRT_FORCE_SLICES");          // tuning aid
         // Beside the frames of other contexts (a slot of an mrt_sequence) the GPU is full whatever
         // this frame's wave count, and what shorter waves cost in set-up is no longer paid back:
         // about 48 K waves measured best with two frames in flight (1080p 0.343 -> 0.313 ms per
         // frame, 4K 1.095 -> 1.063, 8K 4.09 -> 4.07).
         const uint32_t target = (ctx->flags & MRT_IFLAG_IN_FLIGHT) ? 49152u : 131072u;
-        uint32_t want = force ? (uint32_t)std::atoi(force) : (target + waves - 1) / waves;
+        uint32_t want = ctx->force_slices ? ctx->force_slices : (target + waves - 1) / waves;
         if (want > units) want = units;
         if (want > 1) {
             const uint32_t per = (units + want - 1) / want;
@@ -493,10 +526,13 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     ctx->last_slices = p.prim_slices;
     ctx->last_pitch = pitch;
     // Every frame, whatever planes it worked in, reads the per-view records: mrt_set_camera orders
-    // its rebuild behind this event.
-    HIP_TRY(ctx, hipEventRecord(ctx->frame_done, stream));
-    ctx->last_stream = stream;
-    ctx->frame_pending = true;
+    // its rebuild behind this event.  Not for a captured frame: an event recorded into a graph
+    // is no longer one that other streams may wait on, and the replays are the caller's to order.
+    if (!capturing) {
+        HIP_TRY(ctx, hipEventRecord(ctx->frame_done, stream));
+        ctx->last_stream = stream;
+        ctx->frame_pending = true;
+    }
     return MRT_OK;
 }
 
@@ -552,6 +588,9 @@ extern "C" void* mrt_stage_buffer_(mrt_ctx* ctx, int slot, size_t bytes) {
 extern "C" void* mrt_stage_event_(mrt_ctx* ctx, int which) { return (void*)ctx->ev[which & 1]; }
 extern "C" void mrt_stage_set_kernel_ms_(mrt_ctx* ctx, double ms) { ctx->stage_kernel_ms = ms; }
 extern "C" double mrt_stage_get_kernel_ms_(const mrt_ctx* ctx) { return ctx->stage_kernel_ms; }
+// Tests and tuning scripts: cut the primitive list of this ctx's frames into n slices / layers
+// (clamped to what the frame allows), 0 = the automatic choice.  Not part of the public ABI.
+extern "C" void mrt_set_slices_override_(mrt_ctx* ctx, uint32_t n) { if (ctx) ctx->force_slices = n > 65536u ? 65536u : n; }
 // Shared with mrt_accel.hip (mrt_internal.hpp).
 extern "C" const mrt::RenderParams* mrt_ctx_params_(const mrt_ctx* ctx) { return &ctx->params; }
 extern "C" void* mrt_ctx_stream_(const mrt_ctx* ctx) { return (void*)ctx->stream; }
@@ -589,6 +628,11 @@ int mrt_create_internal_(const mrt_config* cfg, mrt_ctx** out) {
     mrt_ctx* ctx = new mrt_ctx();
     ctx->device = dev;
     ctx->flags = cfg ? cfg->flags : 0;
+    if (const char* force = std::getenv("MRT_FORCE_SLICES")) {
+        char* end = nullptr;
+        const long v = std::strtol(force, &end, 10);
+        if (end != force && *end == '\0' && v >= 1 && v <= 65536) ctx->force_slices = (uint32_t)v;
+    }
     auto bail = [&](const char* what, hipError_t err) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(err);
         mrt_destroy(ctx);
@@ -796,11 +840,11 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
         lights[2 * (size_t)k + 1] = make_float4(s->light[3][k], s->light[4][k], s->light[5][k], 0.f);
     }
 
-    if ((rc = upload(ctx, ctx->d_tri_exact, exact)) != MRT_OK) return rc;
-    if ((rc = upload(ctx, ctx->d_sph, sph)) != MRT_OK) return rc;
-    if ((rc = upload(ctx, ctx->d_sph_mat, sph_mat)) != MRT_OK) return rc;
-    if ((rc = upload(ctx, ctx->d_mats, mats)) != MRT_OK) return rc;
-    if ((rc = upload(ctx, ctx->d_lights, lights)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_tri_exact, ctx->cap_tri_exact, exact)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_sph, ctx->cap_sph, sph)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_sph_mat, ctx->cap_sph_mat, sph_mat)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_mats, ctx->cap_mats, mats)) != MRT_OK) return rc;
+    if ((rc = upload(ctx, ctx->d_lights, ctx->cap_lights, lights)) != MRT_OK) return rc;
 
     RenderParams& p = ctx->params;
     std::memset(&p, 0, sizeof p);
@@ -819,6 +863,7 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     // The staging vectors above are pageable and die with this call.
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev[1]));
+    ctx->records_pending = false;              // the record kernels ran before ev[1]
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->upload_ms = ms;
@@ -849,6 +894,17 @@ int mrt_set_camera(mrt_ctx* ctx, const mrt_camera* cam) {
     int rc = rebuild_view(ctx, false);
     if (rc != MRT_OK) return rc;
     ctx->have_scene = true;
+    return MRT_OK;
+}
+
+int mrt_synchronize(mrt_ctx* ctx) {
+    if (!ctx) return MRT_ERR_INVALID;
+    ENTER_DEVICE(ctx);
+    if (ctx->records_pending) HIP_TRY(ctx, hipEventSynchronize(ctx->records_ready));
+    ctx->records_pending = false;
+    if (ctx->frame_pending) HIP_TRY(ctx, hipEventSynchronize(ctx->frame_done));
+    ctx->frame_pending = false;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MRT_OK;
 }
 

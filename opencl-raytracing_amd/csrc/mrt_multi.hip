@@ -309,6 +309,9 @@ int mrt_multi_render_rgba8(mrt_multi* m, uint8_t* host_out, mrt_multi_stats* sta
     const size_t band_bytes = (size_t)m->band_rows * line;
     const uint32_t n_bands = (m->yres + m->band_rows - 1) / m->band_rows;
 
+    // Steps 1-3 only enqueue; whatever they return, every rank's stream is drained before this call
+    // does (a failure half-way must not leave copies into host_out running behind the caller's back).
+    auto enqueue = [&]() -> int {
     // 1. every GPU renders its bands, all at once
     for (uint32_t r = 0; r < world; ++r) {
         Rank& k = m->ranks[r];
@@ -362,6 +365,16 @@ int mrt_multi_render_rgba8(mrt_multi* m, uint8_t* host_out, mrt_multi_stats* sta
             MHIP(m, hipMemcpyAsync(host_out + row0 * line, m->gathered + (size_t)r * m->stride + local_off, bytes,
                                    hipMemcpyDeviceToHost, root.stream));
         }
+    }
+    return MRT_OK;
+    };
+    const int enq = enqueue();
+    if (enq != MRT_OK) {
+        const std::string why = m->err;                     // the first failure is the one reported
+        for (uint32_t r = 0; r < world; ++r)
+            if (hipSetDevice(m->ranks[r].device) == hipSuccess) (void)hipStreamSynchronize(m->ranks[r].stream);
+        (void)hipGetLastError();
+        return mfail(m, enq, why);
     }
     for (uint32_t r = 0; r < world; ++r) {
         MHIP(m, hipSetDevice(m->ranks[r].device));

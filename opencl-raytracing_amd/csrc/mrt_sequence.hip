@@ -105,6 +105,10 @@ int mrt_sequence_create(const mrt_sequence_config* cfg, mrt_sequence** out) {
         mrt_sequence_destroy(q);
         return qfail(nullptr, MRT_ERR_INVALID, "reserved flag bits set in mrt_sequence_config.flags");
     }
+    if (cfg && (cfg->flags & MRT_FLAG_TRACE_NARROW) && (cfg->flags & MRT_FLAG_TRACE_WIDE)) {
+        mrt_sequence_destroy(q);
+        return qfail(nullptr, MRT_ERR_INVALID, "MRT_FLAG_TRACE_NARROW and MRT_FLAG_TRACE_WIDE exclude each other");
+    }
     for (uint32_t k = 0; k < n; ++k) {
         mrt_config c = {cfg ? cfg->device : -1, cfg ? cfg->flags : 0u};
         if (k > 0) c.device = q->device;                 // "-1" must mean the same GPU for every slot
@@ -219,11 +223,21 @@ int mrt_sequence_submit_host(mrt_sequence* q, const mrt_camera* view, uint8_t* h
     } while (0)
     QHIP(hipSetDevice(q->device));
     if (q->lanes.empty()) {
-        q->lanes.resize(2 * q->slots.size());
-        for (HostLane& l : q->lanes) {
-            QHIP(hipEventCreateWithFlags(&l.rendered, hipEventDisableTiming));
-            QHIP(hipEventCreateWithFlags(&l.copied, hipEventDisableTiming));
+        // built aside and adopted only when every event exists: a failure leaves no half-made lanes
+        std::vector<HostLane> lanes(2 * q->slots.size());
+        hipError_t made = hipSuccess;
+        for (HostLane& l : lanes) {
+            if (made == hipSuccess) made = hipEventCreateWithFlags(&l.rendered, hipEventDisableTiming);
+            if (made == hipSuccess) made = hipEventCreateWithFlags(&l.copied, hipEventDisableTiming);
         }
+        if (made != hipSuccess) {
+            for (HostLane& l : lanes) {
+                if (l.rendered) (void)hipEventDestroy(l.rendered);
+                if (l.copied) (void)hipEventDestroy(l.copied);
+            }
+            return qfail(q, MRT_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(made));
+        }
+        q->lanes.swap(lanes);
     }
     Slot* s = nullptr;
     int rc = next_slot(q, view, &s);

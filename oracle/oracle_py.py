@@ -18,19 +18,20 @@ import mrt_pkg  # noqa: E402
 
 mrt = mrt_pkg.load()
 SO = HERE / "libmrt_oracle.so"
+SO_FMA = HERE / "libmrt_oracle_fma.so"      # same source, multiply-adds contracted (see oracle/Makefile)
 _lib = None
+_lib_fma = None
 
 
 def build():
-    subprocess.run(["make", "-C", str(HERE), "-s"], check=True)
+    subprocess.run(["make", "-C", str(HERE), "-s", "all"], check=True)
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not SO.exists():
+def _load(so):
+    if True:
+        if not so.exists():
             build()
-        L = C.CDLL(str(SO))
+        L = C.CDLL(str(so))
         vp = C.c_void_p
         L.mrt_oracle_render.argtypes = [C.POINTER(mrt.SceneStruct), C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, vp]
         L.mrt_oracle_camera_basis.argtypes = [vp] * 5
@@ -49,13 +50,29 @@ def lib():
         L.Rgb = Rgb
         L.mrt_oracle_flat_shader.argtypes = [vp, C.c_int, Rgb, vp]
         L.mrt_oracle_phong_shader.argtypes = [vp, vp, C.c_int, Rgb, vp, vp, C.c_int, vp]
-        _lib = L
+    return L
+
+
+def lib():
+    """The oracle: one rounding per operator."""
+    global _lib
+    if _lib is None:
+        _lib = _load(SO)
     return _lib
 
 
-def render(scene, rows=None, threads=1, want_rgbf=False):
+def lib_fma():
+    """The contracted build: NOT the oracle, only the measure of the reference's own latitude."""
+    global _lib_fma
+    if _lib_fma is None:
+        _lib_fma = _load(SO_FMA)
+    return _lib_fma
+
+
+def render(scene, rows=None, threads=1, want_rgbf=False, contracted=False):
     """Returns dict(rgba[y,x,4], ids[y,x], t[y,x], rgbf[y,x,3] or None); rows outside
-    the requested range are left zero / -1."""
+    the requested range are left zero / -1.  contracted: through the build whose multiply-adds
+    are fused (lib_fma)."""
     st = scene.struct
     h, w = st.yres, st.xres
     r0, r1 = (0, h) if rows is None else rows
@@ -63,7 +80,7 @@ def render(scene, rows=None, threads=1, want_rgbf=False):
     ids = np.full((h, w), -1, np.int32)
     t = np.full((h, w), -1.0, np.float32)
     rgbf = np.zeros((h, w, 3), np.float32) if want_rgbf else None
-    rc = lib().mrt_oracle_render(C.byref(st), r0, r1, threads, rgba.ctypes.data, ids.ctypes.data,
+    rc = (lib_fma() if contracted else lib()).mrt_oracle_render(C.byref(st), r0, r1, threads, rgba.ctypes.data, ids.ctypes.data,
                                  t.ctypes.data, rgbf.ctypes.data if want_rgbf else None)
     if rc != 0:
         raise RuntimeError("mrt_oracle_render rejected the scene")

@@ -121,3 +121,4 @@ def test_noalloc_leaves_free_memory_alone(mrt):
         assert free1 >= free0, (free0, free1)
     finally:
         ctx.close()
+

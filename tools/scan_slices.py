@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""trace_kernel time against the number of triangle-list slices (MRT_FORCE_SLICES) for both lane
+"""trace_kernel time against the number of triangle-list slices (the override MRT_FORCE_SLICES also sets) for both lane
 shapes.  GPU box only.  usage: scan_slices.py [teatime|soup] XRES YRES [slices ...]"""
-import os
 import sys
 from pathlib import Path
 
@@ -22,10 +21,7 @@ for name, flag in (("narrow", mrt.FLAG_TRACE_NARROW), ("wide", mrt.FLAG_TRACE_WI
     ctx = mrt.Context(device=0, flags=flag)
     ctx.set_scene(scene)
     for n in [0] + counts:
-        if n:
-            os.environ["MRT_FORCE_SLICES"] = str(n)
-        else:
-            os.environ.pop("MRT_FORCE_SLICES", None)
+        ctx.force_slices(n)
         ms, slices = [], 0
         for _ in range(30):
             st = ctx.render_bands_device(64, 0, 1, out.data_ptr(), out.numel() * 4, timed=True)
