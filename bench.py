@@ -22,18 +22,27 @@ Rank 0 prints ONE JSON line.  `value` is the throughput of the library's default
 (trace_kernel: every ray x every primitive, most pairs settled by a conservative per-pixel
 predicate, the reference arithmetic for the survivors).  `roofline` is NOT about that kernel --
 its executed arithmetic is a small fraction of the priced arithmetic -- but about
-full_trace_kernel (MRT_FLAG_FULL_TEST), the kernel that evaluates a general-ray 3x3 solve for
-every (ray, triangle) pair, timed in the same run on the same frame with HIP events on its launch
-stream: algorithmic FLOPs per launch = rays * (4032 * 45 + 2 * 20) (45 per ray-triangle test, 20
-per ray-sphere test, no culling credit) over its mean duration, against the 157.3 TFLOP/s FP32
-vector peak.  The default path is described beside it by flat keys (default_*), among them the
+full_trace_kernel (MRT_FLAG_FULL_TEST), which evaluates the determinants of the 3x3 solve for
+every (ray, triangle) pair of the frame with no rejection in screen space, timed in the same run
+on the same frame with HIP events on its launch stream: algorithmic FLOPs per launch = rays *
+(4032 * 45 + 2 * 20) (45 per ray-triangle test, 20 per ray-sphere test, no culling credit) over
+its mean duration, against the 157.3 TFLOP/s FP32 vector peak.  That kernel is NOT a general-ray
+kernel: primary rays share their origin (pinhole) or direction (orthographic), its per-view
+records fold the shared half in, and per pair it executes 37 of the 45 priced FLOPs
+(`roofline.executed_flops_per_pair`, `roofline.frac_executed`).  The kernel that takes arbitrary
+rays -- an origin and a direction per ray, nothing shared -- is the one behind mrt_stage_intersect;
+`general_ray` times it on the reference's own workload (teatime's 160 000 primary rays as an
+array of rays, 4034 objects) and prices it by the same 45 / 20 FLOPs.  The default path is described beside it by flat keys (default_*), among them the
 executed VALU issue rate as a fraction of the nominal 78.6 T lane-ops/s.  `cpu_baseline` times
 the CPU oracle (oracle/mrt_oracle.c, a restatement of the reference arithmetic -- the reference
 has no CPU path of its own and may not be run) on a bounded row sample of the same frame.
 `secondary` carries the other benchmark configurations; with N > 1 the strong-scaling frames
 (16384^2 soup, 8K teatime: one fixed frame over the N ranks) are also reported as flat soup16k_* /
 teatime8k_* keys, among them *_one_gpu_ms_per_frame (the same frame on rank 0's GPU alone, timed
-in the same run) and *_speedup_vs_one_gpu.
+in the same run) and *_speedup_vs_one_gpu.  With N = 1 the compute side of that scaling curve is
+bounded on the one GPU: *_rank_alone_ms_w{2,4,8} is the device time of the slower of ranks 0 and
+w - 1 rendering its interleaved bands of the frame alone, *_compute_eff_w{2,4,8} = T(whole frame)
+/ (w * that) -- the efficiency w GPUs would reach if the gather cost nothing.
 """
 import argparse
 import json
@@ -49,6 +58,11 @@ sys.path.insert(0, str(ROOT / "tools"))
 
 FLOPS_PER_TRI_TEST = 45.0
 FLOPS_PER_SPH_TEST = 20.0
+# what the kernels execute per (ray, triangle) pair, a fused multiply-add counted as two:
+# full_trace_kernel: two cross products (6 mul + 6 fma) + three dot products (9 fma) + 1 sub
+FULL_TRACE_EXECUTED_FLOPS = 37.0
+# general_intersect_kernel: six dot products (18 fma) + 2 sub
+GENERAL_RAY_EXECUTED_FLOPS = 38.0
 FP32_PEAK_TFLOPS = 157.3          # 256 CU x 128 lanes x 2 FLOP x 2.4 GHz
 VALU_ISSUE_PEAK = 78.6e12         # lane-ops/s: 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
 BAND_ROWS = 64
@@ -272,6 +286,19 @@ def secondary_workloads(env, mkscene):
         host_side_handshake(env, f"one_gpu_{name}")
         env.dist.barrier()
 
+    def rank_alone(scene, name, reps):
+        """One GPU only: the compute side of the strong-scaling curve (tools/time_rank_alone.py)."""
+        if env.world != 1:
+            return
+        import time_rank_alone
+        b = time_rank_alone.strong_scaling_bound(mrt, scene, reps=reps)
+        res[name]["whole_frame_kernel_ms"] = b["full_frame"]["kernel_ms"]
+        for w in (2, 4, 8):
+            res[name][f"rank_alone_ms_w{w}"] = b[f"w{w}"]["rank_alone_ms"]
+            res[name][f"compute_eff_w{w}"] = b[f"w{w}"]["compute_eff"]
+            res[name][f"compute_eff_back_to_back_w{w}"] = b[f"w{w}"]["compute_eff_back_to_back"]
+        res[name]["rank_alone"] = b
+
     # The 16384 x 16384 triangle soup, one frame split over all ranks (strong scaling).
     soup16k = mrt.LoadedScene(text=mkscene.soup(16384, 16384)).copy()
     job = Job(env, soup16k, in_flight=FRAMES_IN_FLIGHT)
@@ -279,12 +306,14 @@ def secondary_workloads(env, mkscene):
     frame_stats(job, "soup16k_16384x16384", steps=3 if env.world == 1 else 10, warmup=1, extra={"scaling": "strong"})
     job.close()
     one_gpu_reference(soup16k, "soup16k_16384x16384", steps=3)
+    rank_alone(soup16k, "soup16k_16384x16384", reps=10)
     # teatime at 7680 x 4320, split over all ranks.
     tea8k = mrt.LoadedScene(text=mkscene.teatime(7680, 4320)).copy()
     job = Job(env, tea8k, in_flight=FRAMES_IN_FLIGHT)
     frame_stats(job, "teatime_8k_7680x4320", steps=5 if env.world == 1 else 20, warmup=2, extra={"scaling": "strong"})
     job.close()
     one_gpu_reference(tea8k, "teatime_8k_7680x4320", steps=5)
+    rank_alone(tea8k, "teatime_8k_7680x4320", reps=20)
     if env.world == 1:
         # The shipped scenes at their native 400 x 400 (the only size the reference itself can render).
         for name in ("scene_2spheres_persp_phong", "scene_gtri_persp_phong", "teatime"):
@@ -376,6 +405,48 @@ def native_multi_gpu(env, mkscene, world):
             if world > 1 and res[key].get("gather") != "host":
                 res[f"{key}_host_copies"] = run(scene, png, "host")
     return res
+
+
+def general_ray(env, reps=12):
+    """mrt_stage_intersect's kernels on the reference's own workload: teatime's 400 x 400 primary
+    rays handed over as an array of arbitrary rays (origin and direction each), 4034 objects in
+    the reference's 144-byte records.  Device time of the call's kernels (HIP events, without the
+    copies either side), median over `reps` calls after two warm-up calls."""
+    import numpy as np
+    sys.path.insert(0, str(ROOT / "tests"))
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import scene_py
+    from test_gpu_stages import make_inputs
+    mrt = env.mrt
+    sc = scene_py.load_scene(ROOT / "scenes" / "teatime.json")
+    pos, vp, cam, objs, _, _ = make_inputs(mrt, sc, 400)
+    ctx = mrt.Context(device=env.dev_index)
+    try:
+        rays = ctx.stage_viewrays(cam, ctx.stage_uv(pos, vp), sc.struct.focal)
+        flt_max = float(np.finfo(np.float32).max)
+        ms = []
+        for k in range(reps + 2):
+            ctx.stage_intersect(objs, rays, flt_max, 0.0)
+            if k >= 2:
+                ms.append(ctx.stage_kernel_ms())
+    finally:
+        ctx.close()
+    ms.sort()
+    med = ms[len(ms) // 2]
+    n_tri = int(objs["is_triangle"].sum())
+    n_sph = len(objs) - n_tri
+    flops = len(rays) * (n_tri * FLOPS_PER_TRI_TEST + n_sph * FLOPS_PER_SPH_TEST)
+    achieved = flops / (med * 1e-3) * 1e-12
+    return {"kernel": "general_intersect_kernel (+ ray bounds, records, finish: every kernel of one mrt_stage_intersect call)",
+            "rays": len(rays), "objects": len(objs), "kernel_ms": med, "best_kernel_ms": ms[0],
+            "prim_tests_per_s": len(rays) * len(objs) / (med * 1e-3),
+            "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
+            "executed_flops_per_pair": GENERAL_RAY_EXECUTED_FLOPS,
+            "frac_executed": achieved / FP32_PEAK_TFLOPS * GENERAL_RAY_EXECUTED_FLOPS / FLOPS_PER_TRI_TEST,
+            "note": "arbitrary rays: origin and direction per ray from memory, caller's t range, objects in any order; "
+                    "per pair six dot products of the ray's (direction, moment, origin) with per-triangle vectors (the "
+                    "four determinants of tri_intersect's Cramer solve) as a conservative filter, the reference's unfused "
+                    "arithmetic for the survivors; bit-identical records to the oracle's per-ray loop"}
 
 
 def host_side_handshake(env, key):
@@ -550,9 +621,16 @@ def main():
                 "exec_issue_frac": (fc["SQ_INSTS_VALU"] * 64.0 / (full_trace * 1e-3) / VALU_ISSUE_PEAK)
                 if fc and "SQ_INSTS_VALU" in fc else None,
                 "counters_source": fsrc,
-                "note": "MRT_FLAG_FULL_TEST kernel on the same frame in the same run: a general-ray 3x3 solve "
-                        "(determinants of tri_intersect) for every (ray, triangle) pair, no screen-space rejection; "
-                        "45 FLOP per ray-triangle test, 20 per ray-sphere test; same pixels as the default path",
+                "executed_flops_per_pair": FULL_TRACE_EXECUTED_FLOPS,
+                "frac_executed": achieved / FP32_PEAK_TFLOPS * FULL_TRACE_EXECUTED_FLOPS / FLOPS_PER_TRI_TEST,
+                "note": "MRT_FLAG_FULL_TEST kernel on the same frame in the same run: the determinants of "
+                        "tri_intersect's 3x3 solve for every (ray, triangle) pair, no screen-space rejection, as a fused "
+                        "conservative filter with the reference's unfused arithmetic for the survivors.  NOT a general-ray "
+                        "kernel: the frame's rays share their origin (pinhole) or direction (orthographic) and the per-view "
+                        "records fold that half in, so per pair it executes 37 of the 45 priced FLOPs (two cross products, "
+                        "three dot products, one subtraction): frac is priced FLOPs over time, frac_executed executed "
+                        "FLOPs over time.  45 FLOP per ray-triangle test, 20 per ray-sphere test; same pixels as the "
+                        "default path.  The arbitrary-ray kernel is `general_ray`",
             },
             "full_test_ms_per_frame": full_elapsed / full_reps * 1e3,
             "full_test_mrays_per_s": total_rays * full_reps / full_elapsed * 1e-6,
@@ -568,6 +646,8 @@ def main():
                             "priced by executed VALU issue rate (SQ_INSTS_VALU x 64 lanes / kernel time / 78.6e12), "
                             "not by algorithmic FLOPs",
         }
+        if world == 1:
+            out["general_ray"] = general_ray(env)
         if host is not None:
             out["host_frame"] = host
             cam_t = set_camera_cost(env, sc)
@@ -588,6 +668,9 @@ def main():
                     if "speedup_vs_one_gpu" in sec[name]:
                         out[f"{key}_one_gpu_ms_per_frame"] = sec[name]["one_gpu_ms_per_frame"]
                         out[f"{key}_speedup_vs_one_gpu"] = sec[name]["speedup_vs_one_gpu"]
+                    for k2, v2 in sec[name].items():
+                        if k2.startswith(("rank_alone_ms_w", "compute_eff_w", "whole_frame_kernel_ms")):
+                            out[f"{key}_{k2}"] = v2
     if not args.no_secondary:
         if env.use_dist:
             torch.cuda.synchronize(env.dev)

@@ -241,8 +241,7 @@ int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uin
                             mrt_stats *stats);
 
 /* mrt_render_bands_device for callers that cannot allocate device memory
- * (code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc): same arguments without stats, same pixels, but the closest-hit
+ * (tight serving loops, harnesses that forbid hipMalloc): same arguments without stats, same pixels, but the closest-hit
  * key plane the trace kernel works in lives in a fixed array inside the
  * library instead of a buffer the ctx grows on demand, and the call makes no
  * hipMalloc / hipFree (nor any other allocating call).  The array holds
@@ -255,20 +254,16 @@ int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uin
  * one GPU, from whatever ctx, shares that GPU's array: two such frames in
  * flight at once on one GPU race; enqueue them on one stream or synchronise
  * between them.
- * HIP graph capture: a call on a stream that is capturing (hipStreamBeginCapture)
- * records this frame -- the view and scene current at that moment, with the
- * device addresses of the scene, of its per-view records and of dev_out, and a
- * clearing of the part of the fixed array the frame uses -- and the graph can
- * be replayed any number of times.  Nothing of the ctx may be pending on another
- * stream when the capture begins (mrt_synchronize after the last mrt_set_camera;
- * MRT_ERR_INVALID otherwise, the capture stays valid): a capturing stream cannot
- * wait for work outside its graph.  The call records none of the ctx's events,
- * so mrt_set_camera, mrt_set_scene and
- * frames on other streams are NOT ordered behind replays by the library: the
- * caller synchronises between a replay and any of them.  Capture again after
- * mrt_set_camera (the view is part of the recorded kernel arguments) and after
- * mrt_set_scene (a scene of other counts moves the buffers).  The allocating
- * entry points refuse a capturing stream with MRT_ERR_INVALID.
+ * Not allocating is all it promises.  HIP graph capture is NOT supported: on a
+ * stream that is capturing (hipStreamBeginCapture) this call -- like every other
+ * entry point that takes a stream -- fails with MRT_ERR_INVALID before it
+ * enqueues anything, and the capture stays valid.  Replaying a recorded frame
+ * ended in a GPU memory fault each of the three times it was tried (with the
+ * default and with the MRT_FLAG_FULL_TEST kernels, through torch.cuda.graph and
+ * through hipStreamBeginCapture directly); what the recordings had in common --
+ * a memset node on the fixed array, which is a __device__ symbol and not a
+ * hipMalloc'ed buffer, and kernels that take a 300-byte structure by value --
+ * was not taken apart further.
  * No counterpart in the reference, which allocates in every stage call
  * (CLHelpers.hpp:93-104). */
 #define MRT_NOALLOC_MAX_KEYS (8u * 1024u * 1024u)

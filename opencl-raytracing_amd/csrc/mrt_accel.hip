@@ -707,6 +707,8 @@ int mrt_accel_render_bands_device(mrt_accel* a, uint32_t band_rows, uint32_t ran
     if (((uintptr_t)dev_out & 3u) != 0) return afail(a, MRT_ERR_INVALID, "dev_out must be 4-byte aligned");
     AccelDeviceGuard guard(a->device);
     AHIP_TRY(a, guard.err);
+    if (mrt_stream_is_capturing_(hip_stream))
+        return afail(a, MRT_ERR_INVALID, "the stream is capturing a HIP graph: frames cannot be recorded into a graph (not supported)");
     int rc = launch_grid_frame(a, band_rows, rank, world, (uint32_t*)dev_out, (hipStream_t)hip_stream, stats != nullptr, false);
     if (rc != MRT_OK) return rc;
     if (stats) {

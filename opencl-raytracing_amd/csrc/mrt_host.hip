@@ -187,8 +187,7 @@ void free_dev(void*& p) {
 }
 
 // Copies `src` into the device buffer `dst` of `cap` bytes, which is replaced only when the size
-// changes: a scene of the same shape keeps its device addresses (a captured HIP graph of a frame
-// holds them).
+// changes: a scene of the same shape keeps its device addresses and costs no allocation.
 template <typename T>
 int upload(mrt_ctx* ctx, void*& dst, size_t& cap, const std::vector<T>& src) {
     size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
@@ -297,13 +296,12 @@ struct FramePlanes {
 // on `stream`.
 int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world, uint32_t* dev_out,
                  hipStream_t stream, bool timed, const FramePlanes& planes) {
-    // A frame recorded into a HIP graph: only the entry point that allocates nothing and keeps no
-    // per-frame state on the host can be replayed (the others grow buffers, skip the clearing of
-    // planes they know to be clean, and time with events of the ctx).
-    const bool capturing = stream_is_capturing(stream);
-    if (capturing && (planes.own || timed))
+    // A stream that is recording a HIP graph is refused: replaying a recorded frame ended in a GPU
+    // memory fault every time it was tried (default and full-test kernels alike), so the call
+    // fails cleanly here, before anything is enqueued, and the capture stays valid.
+    if (stream_is_capturing(stream))
         return fail(ctx, MRT_ERR_INVALID,
-                    "the stream is capturing a HIP graph: only mrt_render_bands_device_noalloc can be captured");
+                    "the stream is capturing a HIP graph: frames cannot be recorded into a graph (not supported)");
     RenderParams p = ctx->params;
     p.band_rows = band_rows;
     p.rank = rank;
@@ -390,13 +388,6 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         d_id = ctx->d_id;
     }
     // The planes are shared by all frames of this ctx: a frame on another stream waits for the last one.
-    // A capturing stream must not wait on an event recorded outside its graph (the wait would be
-    // refused, or draw the other stream into the capture), nor may the host wait for one while
-    // it captures: whatever the frame depends on must be over before the capture begins.
-    if (capturing && ((ctx->frame_pending && stream != ctx->last_stream) || (ctx->records_pending && stream != ctx->stream)))
-        return fail(ctx, MRT_ERR_INVALID,
-                    "work of this context is still pending on another stream (mrt_set_camera, or a frame): "
-                    "call mrt_synchronize before capturing");
     if (ctx->frame_pending && stream != ctx->last_stream)
         HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->frame_done, 0));
     // The per-view records are built on the ctx's own stream.
@@ -526,13 +517,10 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     ctx->last_slices = p.prim_slices;
     ctx->last_pitch = pitch;
     // Every frame, whatever planes it worked in, reads the per-view records: mrt_set_camera orders
-    // its rebuild behind this event.  Not for a captured frame: an event recorded into a graph
-    // is no longer one that other streams may wait on, and the replays are the caller's to order.
-    if (!capturing) {
-        HIP_TRY(ctx, hipEventRecord(ctx->frame_done, stream));
-        ctx->last_stream = stream;
-        ctx->frame_pending = true;
-    }
+    // its rebuild behind this event.
+    HIP_TRY(ctx, hipEventRecord(ctx->frame_done, stream));
+    ctx->last_stream = stream;
+    ctx->frame_pending = true;
     return MRT_OK;
 }
 
@@ -592,6 +580,7 @@ extern "C" double mrt_stage_get_kernel_ms_(const mrt_ctx* ctx) { return ctx->sta
 // (clamped to what the frame allows), 0 = the automatic choice.  Not part of the public ABI.
 extern "C" void mrt_set_slices_override_(mrt_ctx* ctx, uint32_t n) { if (ctx) ctx->force_slices = n > 65536u ? 65536u : n; }
 // Shared with mrt_accel.hip (mrt_internal.hpp).
+extern "C" int mrt_stream_is_capturing_(void* hip_stream) { return stream_is_capturing((hipStream_t)hip_stream) ? 1 : 0; }
 extern "C" const mrt::RenderParams* mrt_ctx_params_(const mrt_ctx* ctx) { return &ctx->params; }
 extern "C" void* mrt_ctx_stream_(const mrt_ctx* ctx) { return (void*)ctx->stream; }
 extern "C" int mrt_ctx_projection_(const mrt_ctx* ctx) { return ctx->projection; }

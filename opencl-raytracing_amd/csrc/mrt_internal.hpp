@@ -24,4 +24,6 @@ const mrt::RenderParams* mrt_ctx_params_(const mrt_ctx* ctx);
 void* mrt_ctx_stream_(const mrt_ctx* ctx);
 int mrt_ctx_projection_(const mrt_ctx* ctx);
 int mrt_stage_device_(const mrt_ctx* ctx);
+// Whether the hipStream_t is recording into a HIP graph (such streams are refused by every entry point).
+int mrt_stream_is_capturing_(void* hip_stream);
 }

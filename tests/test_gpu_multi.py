@@ -132,3 +132,30 @@ def test_cli_multi_gpu_writes_the_same_png(tmp_path):
     env = dict(os.environ, MRT_GPU_LIST="0,9")
     r = subprocess.run([str(cli), str(scene), str(host)], capture_output=True, text=True, env=env)
     assert r.returncode == 1 and "render failed" in r.stderr
+
+
+def test_timed_rank_buffers_equal_the_whole_frames_rows(mrt):
+    """What tools/time_rank_alone.py and bench.py time as "one rank alone" -- rank 0 and rank
+    world - 1 of 2, 4 and 8 rendering their interleaved 64-row bands with the timed call -- is the
+    rank's share of the frame: every buffer equals the rows band b = rank, rank + world, ... of
+    the whole frame, on the 8K teatime frame and on the soup (at 4096^2; its 16384^2 rows are held
+    to the oracle by test_soup_16k_rows_against_oracle)."""
+    import torch
+    for text in (mkscene.teatime(7680, 4320), mkscene.soup(4096, 4096)):
+        sc = mrt.LoadedScene(text=text).copy()
+        st = sc.struct
+        whole = _single(mrt, sc)
+        ctx = mrt.Context(device=0)
+        try:
+            ctx.set_scene(sc)
+            for world in (2, 4, 8):
+                for rank in (0, world - 1):
+                    rows = mrt.band_rows(st.yres, 64, rank, world)
+                    buf = torch.zeros(rows * st.xres * 4, dtype=torch.uint8, device="cuda:0")
+                    s = ctx.render_bands_device(64, rank, world, buf.data_ptr(), buf.numel(), timed=True)
+                    assert s.rays == rows * st.xres and s.trace_ms > 0
+                    got = buf.cpu().numpy().reshape(rows, st.xres, 4)
+                    want = np.concatenate([whole[b * 64:(b + 1) * 64] for b in range(rank, (st.yres + 63) // 64, world)])
+                    assert np.array_equal(got, want), (st.xres, world, rank)
+        finally:
+            ctx.close()

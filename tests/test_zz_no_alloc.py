@@ -122,3 +122,63 @@ def test_noalloc_leaves_free_memory_alone(mrt):
     finally:
         ctx.close()
 
+
+def _hip():
+    """The HIP runtime the process already runs on (torch's copy, which libmrt_hip.so binds to)."""
+    import ctypes as C
+    import os
+    import torch
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    vp = C.c_void_p
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]
+    hip.hipStreamDestroy.argtypes = [vp]
+    hip.hipStreamBeginCapture.argtypes = [vp, C.c_int]
+    hip.hipStreamEndCapture.argtypes = [vp, C.POINTER(vp)]
+    hip.hipGraphDestroy.argtypes = [vp]
+    hip.hipStreamSynchronize.argtypes = [vp]
+    return hip
+
+
+def test_capturing_streams_are_refused(mrt):
+    """HIP graph capture is not supported: on a stream that is recording a graph every entry point
+    that takes a stream fails with MRT_ERR_INVALID before it enqueues anything, the capture stays
+    valid and comes out empty, and the context goes on rendering afterwards.  (Nothing recorded is
+    ever launched here.)"""
+    import ctypes as C
+    import torch
+    hip = _hip()
+    sc = mrt.LoadedScene(text=mkscene.teatime(640, 360)).copy()
+    nbytes = 640 * 360 * 4
+    stream = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(stream), 1) == 0            # non-blocking
+    ctx = mrt.Context(device=0)
+    grid = mrt.Accel(device=0, method="grid")
+    try:
+        ctx.set_scene(sc)
+        grid.set_scene(sc)
+        ref = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+        out = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device="cuda:0")
+        ctx.render_bands_device(360, 0, 1, ref.data_ptr(), nbytes, stream=stream.value)
+        assert hip.hipStreamSynchronize(stream) == 0
+        ctx.synchronize()
+        graph = C.c_void_p()
+        assert hip.hipStreamBeginCapture(stream, 1) == 0                    # thread-local mode
+        for call in (lambda: ctx.render_bands_device_noalloc(360, 0, 1, out.data_ptr(), nbytes, stream=stream.value),
+                     lambda: ctx.render_bands_device(360, 0, 1, out.data_ptr(), nbytes, stream=stream.value),
+                     lambda: grid.render_bands_device(360, 0, 1, out.data_ptr(), nbytes, stream=stream.value)):
+            with pytest.raises(mrt.MrtError) as e:
+                call()
+            assert e.value.code == -1 and "captur" in e.value.message
+        assert hip.hipStreamEndCapture(stream, C.byref(graph)) == 0          # the refusals left it valid
+        if graph.value:
+            assert hip.hipGraphDestroy(graph) == 0
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy() == 0x5A).all()                            # nothing ran, nothing was recorded
+        ctx.render_bands_device_noalloc(360, 0, 1, out.data_ptr(), nbytes, stream=stream.value)
+        assert hip.hipStreamSynchronize(stream) == 0
+        assert np.array_equal(out.cpu().numpy(), ref.cpu().numpy())
+    finally:
+        hip.hipStreamSynchronize(stream)
+        ctx.close()
+        grid.close()
+        hip.hipStreamDestroy(stream)

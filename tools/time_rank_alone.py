@@ -57,6 +57,29 @@ def rank_alone(mrt, scene, world, rank, reps, flags=0):
             "kernel": int(ev[0][3]), "slices": int(ev[0][4])}
 
 
+def strong_scaling_bound(mrt, scene, reps=10, worlds=(2, 4, 8), flags=0, log=None):
+    """The whole frame and, for every world size, ranks 0 and world - 1 alone on the GPU.  Returns
+    {"full_frame": {...}, "w<world>": {"rank_alone_ms": slowest of the two ranks (device time),
+    "compute_eff": T(whole frame) / (world * that), "ranks": {...}}}."""
+    full = rank_alone(mrt, scene, 1, 0, reps, flags)
+    res = {"full_frame": full}
+    if log:
+        log(f"whole frame: {full}")
+    for world in worlds:
+        ranks = {}
+        for rank in sorted({0, world - 1}):
+            ranks[rank] = rank_alone(mrt, scene, world, rank, reps, flags)
+            if log:
+                log(f"world {world} rank {rank}: {ranks[rank]}")
+        slow = max(r["kernel_ms"] for r in ranks.values())
+        slow_b2b = max(r["back_to_back_ms"] for r in ranks.values())
+        res[f"w{world}"] = {"rank_alone_ms": slow, "compute_eff": full["kernel_ms"] / (world * slow),
+                            "rank_alone_back_to_back_ms": slow_b2b,
+                            "compute_eff_back_to_back": full["back_to_back_ms"] / (world * slow_b2b),
+                            "ranks": {str(k): v for k, v in ranks.items()}}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="?", default="both")
@@ -75,16 +98,12 @@ def main():
     res = {}
     for name, text in frames:
         scene = mrt.LoadedScene(text=text).copy()
-        full = rank_alone(mrt, scene, 1, 0, args.reps, args.flags)
-        res[name] = {"full_frame": full}
-        print(f"{name} whole frame: {full}", flush=True)
+        res[name] = strong_scaling_bound(mrt, scene, args.reps, flags=args.flags,
+                                         log=lambda m, n=name: print(n, m, flush=True))
         for world in (2, 4, 8):
-            for rank in sorted({0, world - 1}):
-                r = rank_alone(mrt, scene, world, rank, args.reps, args.flags)
-                r["compute_eff_kernel"] = full["kernel_ms"] / (world * r["kernel_ms"])
-                r["compute_eff_back_to_back"] = full["back_to_back_ms"] / (world * r["back_to_back_ms"])
-                res[name][f"w{world}_r{rank}"] = r
-                print(f"{name} world {world} rank {rank}: {r}", flush=True)
+            e = res[name][f"w{world}"]
+            print(f"{name} world {world}: rank alone {e['rank_alone_ms']:.3f} ms, compute efficiency {e['compute_eff']:.3f} "
+                  f"(back to back {e['compute_eff_back_to_back']:.3f})", flush=True)
     if args.json:
         Path(args.json).write_text(json.dumps(res, indent=1))
 
