@@ -230,6 +230,13 @@ int mrt_render_debug(mrt_ctx *ctx, uint8_t *host_out, int32_t *ids, float *t,
  * mrt_band_rows() returns how many image rows rank owns.
  */
 uint32_t mrt_band_rows(uint32_t yres, uint32_t band_rows, uint32_t rank, uint32_t world);
+/* The band height, 64 rows or 32 (whole wave tiles), that leaves the busiest of
+ * `world` ranks the fewer rows of a yres-row image (64 when it makes no difference):
+ * 32 for 4320 rows over 8 ranks, where
+ * bands of 64 would give one rank 576 rows against a mean of 540.  The frame is as
+ * slow as its busiest rank.  (Takes the place of the reference's single-device
+ * choice, CLHelpers.hpp:28-45, like the rest of the band partition.) */
+uint32_t mrt_balanced_band_rows(uint32_t yres, uint32_t world);
 
 /* Render only this rank's bands into DEVICE memory (dev_out, at least
  * mrt_band_rows()*xres*4 bytes), asynchronously on hip_stream (a hipStream_t,
@@ -297,7 +304,7 @@ typedef struct mrt_multi_config {
                                  several ranks then share a GPU (a rehearsal of N ranks on fewer
                                  GPUs; RCCL cannot be used then)                                  */
     uint32_t flags;           /* MRT_FLAG_* for every rank                                        */
-    uint32_t band_rows;       /* rows per band, 0 = 64                                            */
+    uint32_t band_rows;       /* rows per band, 0 = mrt_balanced_band_rows of every frame's height   */
     uint32_t gather;          /* MRT_GATHER_*                                                     */
 } mrt_multi_config;
 

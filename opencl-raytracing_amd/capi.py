@@ -33,7 +33,7 @@ SHADER_FLAT, SHADER_PHONG = 0, 1
 # Every symbol include/mrt.h declares.
 EXPORTED_SYMBOLS = [
     "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_abi_version", "mrt_set_scene", "mrt_set_camera",
-    "mrt_render_rgba8", "mrt_render_debug", "mrt_band_rows", "mrt_render_bands_device",
+    "mrt_render_rgba8", "mrt_render_debug", "mrt_band_rows", "mrt_balanced_band_rows", "mrt_render_bands_device",
     "mrt_bands_to_image", "mrt_scene_load_file", "mrt_scene_load_text", "mrt_scene_view",
     "mrt_scene_info_view", "mrt_scene_free", "mrt_write_png_rgb", "mrt_stage_uv",
     "mrt_stage_ortho_viewrays", "mrt_stage_persp_viewrays", "mrt_stage_intersect",
@@ -223,6 +223,8 @@ def lib():
     L.mrt_host_free.restype = None
     L.mrt_band_rows.argtypes = [C.c_uint32] * 4
     L.mrt_band_rows.restype = C.c_uint32
+    L.mrt_balanced_band_rows.argtypes = [C.c_uint32] * 2
+    L.mrt_balanced_band_rows.restype = C.c_uint32
     L.mrt_render_bands_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp,
                                           C.POINTER(Stats)]
     L.mrt_render_bands_device_noalloc.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
@@ -746,6 +748,11 @@ def host_array(shape, dtype=np.uint8):
 
 def band_rows(yres, rows_per_band, rank, world):
     return int(lib().mrt_band_rows(yres, rows_per_band, rank, world))
+
+
+def balanced_band_rows(yres, world):
+    """mrt_balanced_band_rows: the band height (64 or 32 rows) that balances the ranks best."""
+    return int(lib().mrt_balanced_band_rows(yres, world))
 
 
 def bands_to_image(gathered: np.ndarray, stride_bytes, xres, yres, rows_per_band, world):

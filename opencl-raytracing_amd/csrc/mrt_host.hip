@@ -908,6 +908,23 @@ uint32_t mrt_band_rows(uint32_t yres, uint32_t band_rows, uint32_t rank, uint32_
     return (uint32_t)rows;
 }
 
+uint32_t mrt_balanced_band_rows(uint32_t yres, uint32_t world) {
+    if (yres == 0 || world <= 1) return 64;
+    // the band height (a multiple of the 32 rows of a wave tile -- bands that cut tiles cost more
+    // than they balance: 8K over two ranks 2.5 % slower with bands of 48 rows than of 64 -- and at
+    // most 64) that leaves the busiest rank the fewest rows; among equals the tallest
+    uint32_t best = 64, best_rows = 0xFFFFFFFFu;
+    for (uint32_t b = 64; b >= 32; b -= 32) {
+        uint32_t most = 0;
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint32_t rows = mrt_band_rows(yres, b, r, world);
+            if (rows > most) most = rows;
+        }
+        if (most < best_rows) { best_rows = most; best = b; }
+    }
+    return best;
+}
+
 int mrt_render_bands_device(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world,
                             void* dev_out, size_t dev_out_bytes, void* hip_stream, mrt_stats* stats) {
     if (!ctx) return MRT_ERR_INVALID;

@@ -83,6 +83,7 @@ struct Rank {
 struct mrt_multi {
     std::vector<Rank> ranks;
     uint32_t band_rows = 64;
+    uint32_t band_rows_asked = 0;            // what the config said: 0 = balanced for every frame height
     uint32_t gather = MRT_GATHER_PEER;
     uint32_t flags = 0;
     std::string err, note;
@@ -127,6 +128,7 @@ void release_buffers(mrt_multi* m) {
 // transports, world slots on rank 0's GPU (whose first slot is rank 0's own buffer).
 int ensure_buffers(mrt_multi* m) {
     const uint32_t world = (uint32_t)m->ranks.size();
+    if (!m->band_rows_asked) m->band_rows = mrt_balanced_band_rows(m->yres, world);
     uint32_t most = 0;
     for (uint32_t r = 0; r < world; ++r) {
         const uint32_t rows = mrt_band_rows(m->yres, m->band_rows, r, world);
@@ -202,7 +204,8 @@ int mrt_multi_create(const mrt_multi_config* cfg, mrt_multi** out) {
     }
     CurrentDevice keep;
     mrt_multi* m = new mrt_multi();
-    m->band_rows = (cfg && cfg->band_rows) ? cfg->band_rows : 64u;
+    m->band_rows_asked = cfg ? cfg->band_rows : 0u;
+    m->band_rows = m->band_rows_asked ? m->band_rows_asked : 64u;
     m->flags = cfg ? cfg->flags : 0u;
     m->ranks.resize(world);
     auto bail = [&](int code, const std::string& msg) {
