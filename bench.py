@@ -100,13 +100,14 @@ def cpu_baseline(sc, seconds_target=12.0):
     }
 
 
-def profiled_counters(kernel):
+def profiled_counters(kernel, name="teatime4k"):
     """Mean hardware counters per launch of one kernel from the newest committed rocprofv3 passes
     of this same command (profiles/rNN/teatime4k_pmc_summary.json, made by tools/profile.sh and
-    tools/summarize_profile.py), or (None, None).  The summary has an entry per launch shape; the
+    tools/summarize_profile.py; name = soup16k / teatime8k / stage_intersect: the passes of
+    tools/profile_frames.sh and tools/profile_stages.sh), or (None, None).  The summary has an entry per launch shape; the
     one with the largest grid is a whole frame of one context, which is what the kernel times
     quoted beside the counters are measured on."""
-    for f in sorted((ROOT / "profiles").glob("r*/teatime4k_pmc_summary.json"), reverse=True):
+    for f in sorted((ROOT / "profiles").glob(f"r*/{name}_pmc_summary.json"), reverse=True):
         try:
             found = [e for name, e in json.loads(f.read_text()).items() if kernel in name]
             if found:
@@ -437,7 +438,10 @@ def general_ray(env, reps=12):
     n_sph = len(objs) - n_tri
     flops = len(rays) * (n_tri * FLOPS_PER_TRI_TEST + n_sph * FLOPS_PER_SPH_TEST)
     achieved = flops / (med * 1e-3) * 1e-12
-    return {"kernel": "general_intersect_kernel (+ ray bounds, records, finish: every kernel of one mrt_stage_intersect call)",
+    gc, gsrc = profiled_counters("mrt::general_intersect_kernel", "stage_intersect")
+    return {"insts_valu_per_pair": (gc["SQ_INSTS_VALU"] * 64.0 / (len(rays) * len(objs))) if gc and "SQ_INSTS_VALU" in gc else None,
+            "counters_source": gsrc,
+            "kernel": "general_intersect_kernel (+ ray bounds, records, finish: every kernel of one mrt_stage_intersect call)",
             "rays": len(rays), "objects": len(objs), "kernel_ms": med, "best_kernel_ms": ms[0],
             "prim_tests_per_s": len(rays) * len(objs) / (med * 1e-3),
             "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
@@ -660,6 +664,17 @@ def main():
         if rank == 0:
             out["secondary"] = sec
             # strong scaling of one fixed frame over the N ranks, as flat keys
+            if "soup16k_full_test_every_pair" in sec:
+                # the roofline kernel on the other graded frame: 16 384 triangles + 1024 spheres at 16384^2
+                e = sec["soup16k_full_test_every_pair"]
+                sc_, _ = profiled_counters("mrt::full_trace_kernel", "soup16k")
+                pairs = e["xres"] * e["yres"] * e["primitives"]
+                out["soup16k_full_test_kernel_ms"] = e["rank0_trace_kernel_ms"]
+                out["soup16k_full_test_tflops"] = e["rank0_algorithmic_tflops"]
+                out["soup16k_full_test_frac"] = e["rank0_algorithmic_tflops"] / FP32_PEAK_TFLOPS
+                out["soup16k_full_test_frac_executed"] = out["soup16k_full_test_frac"] * FULL_TRACE_EXECUTED_FLOPS / FLOPS_PER_TRI_TEST
+                if sc_ and "SQ_INSTS_VALU" in sc_:
+                    out["soup16k_full_test_insts_valu_per_pair"] = sc_["SQ_INSTS_VALU"] * 64.0 / pairs
             for key, name in (("soup16k", "soup16k_16384x16384"), ("teatime8k", "teatime_8k_7680x4320")):
                 if name in sec:
                     out[f"{key}_ms_per_frame"] = sec[name]["ms_per_frame"]

@@ -209,6 +209,19 @@ int mrt_synchronize(mrt_ctx *ctx);
  * (gfxraytrace.hpp:830-878) and the per-stage calls it makes. */
 int mrt_render_rgba8(mrt_ctx *ctx, uint8_t *host_out, mrt_stats *stats /* may be NULL */);
 
+/* mrt_render_rgba8 for a caller who can use the rows as they arrive (an encoder,
+ * a display): the frame is rendered in strips of strip_rows consecutive rows
+ * (0 = the library's choice, about eight per frame), every strip is copied to
+ * host_out behind its kernels and beside the strips that follow, and
+ * ready(user, row_begin, row_end) is called -- on the calling thread, in row
+ * order -- as soon as rows [row_begin, row_end) of host_out are final.  Same
+ * bytes as mrt_render_rgba8.  stats->trace_ms covers all strips.  host_out is
+ * best page-locked.  Takes the place of the host loops that assemble the image
+ * after the last stage (gfxraytrace.hpp:872-875). */
+typedef void (*mrt_rows_ready_fn)(void *user, uint32_t row_begin, uint32_t row_end);
+int mrt_render_rgba8_rows(mrt_ctx *ctx, uint8_t *host_out, uint32_t strip_rows, mrt_rows_ready_fn ready,
+                          void *user, mrt_stats *stats /* may be NULL */);
+
 /* Page-locked host memory for mrt_render_rgba8's host_out: the device-to-host
  * copy then runs at PCIe rate instead of through the runtime's bounce buffers
  * (about 3x at 3840x2160).  Any other host memory works too.  Takes the place
@@ -334,6 +347,11 @@ int mrt_multi_set_camera(mrt_multi *m, const mrt_camera *camera);
 /* mrt_render_rgba8 over all ranks: same bytes as one GPU renders.  host_out is
  * best page-locked (mrt_host_alloc): the band copies then run asynchronously. */
 int mrt_multi_render_rgba8(mrt_multi *m, uint8_t *host_out, mrt_multi_stats *stats /* may be NULL */);
+/* ... telling the caller of every band as it lands in host_out, in row order
+ * (see mrt_render_rgba8_rows): an encoder fed from `ready` works under the
+ * other bands' copies and the other GPUs' rendering. */
+int mrt_multi_render_rgba8_rows(mrt_multi *m, uint8_t *host_out, mrt_rows_ready_fn ready, void *user,
+                                mrt_multi_stats *stats /* may be NULL */);
 
 /* ------------------------------------------------------------------------
  * Many frames of one scene on one GPU, several of them in flight: a turntable,
@@ -480,6 +498,20 @@ void mrt_scene_free(mrt_loaded_scene *s);
 /* 8-bit RGB PNG (no alpha) from an RGBA8 buffer, the format of
  * gfxpng.hpp:63-86. */
 int mrt_write_png_rgb(const char *path, const uint8_t *rgba, uint32_t xres, uint32_t yres);
+
+/* The same file, encoded while the frame is still arriving: rgba is the whole
+ * xres*yres RGBA8 image buffer, filled by someone else; mrt_png_stream_rows
+ * reports rows [row_begin, row_end) of it final (any order, every row exactly
+ * once), host threads deflate each stripe of rows as soon as it is whole, and
+ * mrt_png_stream_end waits for them, writes the file and frees the stream
+ * (MRT_ERR_INVALID, and no file, if rows were never reported).  Byte for byte
+ * the file mrt_write_png_rgb writes.  gfxpng.hpp:63-86 encodes after the last
+ * pixel is in place; at 16384 x 16384 that is the longest step of the run. */
+typedef struct mrt_png_stream mrt_png_stream;
+int mrt_png_stream_begin(const char *path, const uint8_t *rgba, uint32_t xres, uint32_t yres,
+                         mrt_png_stream **out);
+int mrt_png_stream_rows(mrt_png_stream *s, uint32_t row_begin, uint32_t row_end);
+int mrt_png_stream_end(mrt_png_stream *s);
 
 /* ------------------------------------------------------------------------
  * Stage-level entry points with the reference's own array-of-structs types,

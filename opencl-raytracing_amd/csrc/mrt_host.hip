@@ -143,6 +143,9 @@ struct mrt_ctx {
     // Tuning override of the automatic slice / layer count (0 = automatic): MRT_FORCE_SLICES in the
     // environment when the ctx is created, or mrt_set_slices_override_.
     uint32_t force_slices = 0;
+    // mrt_render_rgba8_rows: a stream for the strip copies and two events per strip
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> strip_events;
 };
 
 namespace {
@@ -657,6 +660,8 @@ void mrt_destroy(mrt_ctx* ctx) {
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     for (int k = 0; k < mrt_ctx::kStageSlots; ++k) if (ctx->stage_buf[k]) (void)hipFree(ctx->stage_buf[k]);
     for (int k = 0; k < 3; ++k) if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    for (hipEvent_t e : ctx->strip_events) if (e) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->frame_done) (void)hipEventDestroy(ctx->frame_done);
     if (ctx->records_ready) (void)hipEventDestroy(ctx->records_ready);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1007,6 +1012,65 @@ int mrt_render_debug(mrt_ctx* ctx, uint8_t* host_out, int32_t* ids, float* t, mr
     local.download_ms = dms;
     if (stats) *stats = local;
     return MRT_OK;
+}
+
+int mrt_render_rgba8_rows(mrt_ctx* ctx, uint8_t* host_out, uint32_t strip_rows, mrt_rows_ready_fn ready, void* user,
+                          mrt_stats* stats) {
+    if (!ctx) return MRT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
+    if (!host_out) return fail(ctx, MRT_ERR_INVALID, "host_out is NULL");
+    ENTER_DEVICE(ctx);
+    const uint32_t xres = ctx->params.xres, yres = ctx->params.yres;
+    const size_t npx = (size_t)xres * yres;
+    if (strip_rows == 0) {
+        // about eight strips, whole block tiles each; a small frame is one strip
+        strip_rows = npx < (2u << 20) ? yres : round_up((yres + 7) / 8, 64);
+    }
+    const uint32_t n_strips = (yres + strip_rows - 1) / strip_rows;
+    int rc = ensure_out(ctx, npx);
+    if (rc != MRT_OK) return rc;
+    if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    while (ctx->strip_events.size() < 2 * (size_t)n_strips) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->strip_events.push_back(e);
+    }
+    // Every strip is a frame of its own on the ctx's stream (band k of n_strips bands of strip_rows
+    // rows belongs to "rank" k); its copy to the host runs on the copy stream, beside the strips
+    // that follow, and the caller hears of it as soon as it has landed.
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    for (uint32_t k = 0; k < n_strips; ++k) {
+        const size_t off = (size_t)k * strip_rows * xres;
+        const uint32_t rows = mrt_band_rows(yres, strip_rows, k, n_strips);
+        rc = launch_frame(ctx, strip_rows, k, n_strips, ctx->d_out + off, ctx->stream, false, FramePlanes{});
+        if (rc != MRT_OK) break;
+        hipEvent_t rendered = ctx->strip_events[2 * k], copied = ctx->strip_events[2 * k + 1];
+        hipError_t e = hipEventRecord(rendered, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, rendered, 0);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(host_out + off * 4, ctx->d_out + off, (size_t)rows * xres * 4, hipMemcpyDeviceToHost, ctx->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(copied, ctx->copy_stream);
+        if (e != hipSuccess) { rc = fail(ctx, MRT_ERR_HIP, std::string("strip copy: ") + hipGetErrorString(e)); break; }
+    }
+    if (rc != MRT_OK) {
+        // nothing may still be writing host_out when the caller sees the error
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        return rc;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    for (uint32_t k = 0; k < n_strips; ++k) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->strip_events[2 * k + 1]));
+        const uint32_t r0 = k * strip_rows;
+        if (ready) ready(user, r0, r0 + mrt_band_rows(yres, strip_rows, k, n_strips));
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
+        rc = fill_stats(ctx, stats, yres);
+    }
+    return rc;
 }
 
 int mrt_render_rgba8(mrt_ctx* ctx, uint8_t* host_out, mrt_stats* stats) {

@@ -84,6 +84,7 @@ struct mrt_multi {
     std::vector<Rank> ranks;
     uint32_t band_rows = 64;
     uint32_t band_rows_asked = 0;            // what the config said: 0 = balanced for every frame height
+    std::vector<BandEvent> band_events;      // mrt_multi_render_rgba8_rows: behind the copy of band b
     uint32_t gather = MRT_GATHER_PEER;
     uint32_t flags = 0;
     std::string err, note;
@@ -301,6 +302,11 @@ int mrt_multi_set_camera(mrt_multi* m, const mrt_camera* camera) {
 }
 
 int mrt_multi_render_rgba8(mrt_multi* m, uint8_t* host_out, mrt_multi_stats* stats) {
+    return mrt_multi_render_rgba8_rows(m, host_out, nullptr, nullptr, stats);
+}
+
+int mrt_multi_render_rgba8_rows(mrt_multi* m, uint8_t* host_out, mrt_rows_ready_fn ready, void* user,
+                                mrt_multi_stats* stats) {
     if (!m) return MRT_ERR_INVALID;
     if (!m->have_scene) return mfail(m, MRT_ERR_NO_SCENE, "mrt_multi_set_scene has not succeeded");
     if (!host_out) return mfail(m, MRT_ERR_INVALID, "host_out is NULL");
@@ -359,14 +365,31 @@ int mrt_multi_render_rgba8(mrt_multi* m, uint8_t* host_out, mrt_multi_stats* sta
         const size_t local_off = (size_t)(b / world) * band_bytes;
         const size_t row0 = (size_t)b * m->band_rows;
         const size_t bytes = ((row0 + m->band_rows <= m->yres) ? m->band_rows : (m->yres - row0)) * line;
-        if (m->gather == MRT_GATHER_HOST) {
-            Rank& k = m->ranks[r];
-            MHIP(m, hipSetDevice(k.device));
-            MHIP(m, hipMemcpyAsync(host_out + row0 * line, k.local + local_off, bytes, hipMemcpyDeviceToHost, k.stream));
-        } else {
-            MHIP(m, hipSetDevice(root.device));
+        Rank& from = m->gather == MRT_GATHER_HOST ? m->ranks[r] : root;
+        MHIP(m, hipSetDevice(from.device));
+        if (m->gather == MRT_GATHER_HOST)
+            MHIP(m, hipMemcpyAsync(host_out + row0 * line, from.local + local_off, bytes, hipMemcpyDeviceToHost, from.stream));
+        else
             MHIP(m, hipMemcpyAsync(host_out + row0 * line, m->gathered + (size_t)r * m->stride + local_off, bytes,
                                    hipMemcpyDeviceToHost, root.stream));
+        if (ready) {
+            // one event per band, on the GPU that copies it (made on first use, kept with the handle)
+            if (m->band_events.size() <= b) m->band_events.resize((size_t)b + 1);
+            BandEvent& be = m->band_events[b];
+            if (be.event && be.device != from.device) { (void)hipEventDestroy(be.event); be.event = nullptr; }
+            if (!be.event) {
+                MHIP(m, hipEventCreateWithFlags(&be.event, hipEventDisableTiming));
+                be.device = from.device;
+            }
+            MHIP(m, hipEventRecord(be.event, from.stream));
+        }
+    }
+    if (ready) {
+        for (uint32_t b = 0; b < n_bands; ++b) {
+            MHIP(m, hipSetDevice(m->band_events[b].device));
+            MHIP(m, hipEventSynchronize(m->band_events[b].event));
+            const uint32_t row0 = b * m->band_rows;
+            ready(user, row0, row0 + m->band_rows <= m->yres ? row0 + m->band_rows : m->yres);
         }
     }
     return MRT_OK;

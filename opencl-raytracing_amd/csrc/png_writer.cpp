@@ -8,15 +8,21 @@
 // stripe ended with a full flush so the pieces concatenate into one zlib
 // stream), and the Adler-32 of the whole image is combined from per-stripe
 // values.  A 16384x16384 frame is ~805 MB of scanlines, which is why this is
-// not done on one thread.
+// not done on one thread -- and why the encoder can start before the frame is
+// complete (mrt_png_stream_*): a stripe is deflated as soon as its rows are in,
+// while the GPUs still render and copy the rest.
 #include "mrt.h"
 
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -92,45 +98,48 @@ void deflate_stripe(const uint8_t* rgba, uint32_t xres, Stripe& st, bool last) {
 
 }  // namespace
 
-extern "C" int mrt_write_png_rgb(const char* path, const uint8_t* rgba, uint32_t xres, uint32_t yres) {
-    if (!path || !rgba || xres == 0 || yres == 0) return MRT_ERR_INVALID;
-
-    const size_t line = 1 + static_cast<size_t>(xres) * 3;
-    // ~4 MB of scanlines per stripe, at least one row.
-    uint32_t rows_per = static_cast<uint32_t>(std::max<size_t>(1, (4u << 20) / line));
-    uint32_t n_stripes = (yres + rows_per - 1) / rows_per;
-    std::vector<Stripe> stripes(n_stripes);
-    for (uint32_t k = 0; k < n_stripes; ++k) {
-        stripes[k].row_begin = k * rows_per;
-        stripes[k].row_end = std::min(yres, (k + 1) * rows_per);
-    }
-    // At most 16 threads (a one-GPU share of a node's cores) unless MRT_PNG_THREADS says otherwise:
-    // a caller who has the whole node (the frame of eight GPUs) can give the encoder more.
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned cap = 16u;
-    if (const char* env = std::getenv("MRT_PNG_THREADS")) {
-        const long v = std::strtol(env, nullptr, 10);
-        if (v >= 1 && v <= 1024) cap = static_cast<unsigned>(v);
-    }
-    unsigned n_threads = std::max(1u, std::min<unsigned>(std::min(hw ? hw : 1u, cap), n_stripes));
+// A PNG being encoded while its pixels are still arriving: the stripes are those of
+// mrt_write_png_rgb (so are the bytes of the file); a stripe is deflated by a pool thread as soon
+// as all of its rows have been reported final.
+struct mrt_png_stream {
+    std::string path;
+    const uint8_t* rgba = nullptr;
+    uint32_t xres = 0, yres = 0, rows_per = 1;
+    std::vector<Stripe> stripes;
+    std::vector<uint32_t> rows_in;          // rows of each stripe reported so far
+    std::deque<uint32_t> runnable;          // stripes whose rows are all in, not yet taken by a thread
+    uint32_t done = 0;                      // stripes deflated (or failed)
+    bool closing = false;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t < n_threads; ++t) {
-        pool.emplace_back([&, t]() {
-            for (uint32_t k = t; k < n_stripes; k += n_threads)
-                deflate_stripe(rgba, xres, stripes[k], k + 1 == n_stripes);
-        });
-    }
-    for (auto& th : pool) th.join();
-    for (const auto& st : stripes)
-        if (!st.ok) return MRT_ERR_IO;
+};
 
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return MRT_ERR_IO;
+namespace {
+
+void stream_worker(mrt_png_stream* s) {
+    std::unique_lock<std::mutex> lock(s->mu);
+    for (;;) {
+        s->cv_work.wait(lock, [&] { return s->closing || !s->runnable.empty(); });
+        if (s->runnable.empty()) return;                        // closing and nothing left
+        const uint32_t k = s->runnable.front();
+        s->runnable.pop_front();
+        lock.unlock();
+        deflate_stripe(s->rgba, s->xres, s->stripes[k], k + 1 == (uint32_t)s->stripes.size());
+        lock.lock();
+        ++s->done;
+        s->cv_done.notify_all();
+    }
+}
+
+bool write_file(const mrt_png_stream& s) {
+    FILE* f = std::fopen(s.path.c_str(), "wb");
+    if (!f) return false;
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     bool ok = std::fwrite(sig, 1, 8, f) == 8;
     uint8_t ihdr[13];
-    be32(ihdr, xres);
-    be32(ihdr + 4, yres);
+    be32(ihdr, s.xres);
+    be32(ihdr + 4, s.yres);
     ihdr[8] = 8;   // bit depth
     ihdr[9] = 2;   // colour type: truecolour (RGB)
     ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
@@ -142,7 +151,7 @@ extern "C" int mrt_write_png_rgb(const char* path, const uint8_t* rgba, uint32_t
     ok = ok && write_chunk(f, "IDAT", zhdr, 2);
     uLong adler = 1;
     bool first = true;
-    for (const auto& st : stripes) {
+    for (const auto& st : s.stripes) {
         size_t off = 0;
         while (ok && off < st.deflated.size()) {   // keep every chunk below 2^31 bytes
             size_t n = std::min<size_t>(st.deflated.size() - off, 1u << 30);
@@ -157,5 +166,90 @@ extern "C" int mrt_write_png_rgb(const char* path, const uint8_t* rgba, uint32_t
     ok = ok && write_chunk(f, "IDAT", ad, 4);
     ok = ok && write_chunk(f, "IEND", nullptr, 0);
     ok = (std::fclose(f) == 0) && ok;
-    return ok ? MRT_OK : MRT_ERR_IO;
+    return ok;
+}
+
+}  // namespace
+
+extern "C" int mrt_png_stream_begin(const char* path, const uint8_t* rgba, uint32_t xres, uint32_t yres,
+                                    mrt_png_stream** out) {
+    if (!out) return MRT_ERR_INVALID;
+    *out = nullptr;
+    if (!path || !rgba || xres == 0 || yres == 0) return MRT_ERR_INVALID;
+    mrt_png_stream* s = new mrt_png_stream();
+    s->path = path;
+    s->rgba = rgba;
+    s->xres = xres;
+    s->yres = yres;
+    const size_t line = 1 + static_cast<size_t>(xres) * 3;
+    // ~4 MB of scanlines per stripe, at least one row.
+    s->rows_per = static_cast<uint32_t>(std::max<size_t>(1, (4u << 20) / line));
+    const uint32_t n_stripes = (yres + s->rows_per - 1) / s->rows_per;
+    s->stripes.resize(n_stripes);
+    s->rows_in.assign(n_stripes, 0u);
+    for (uint32_t k = 0; k < n_stripes; ++k) {
+        s->stripes[k].row_begin = k * s->rows_per;
+        s->stripes[k].row_end = std::min(yres, (k + 1) * s->rows_per);
+    }
+    // At most 16 threads (a one-GPU share of a node's cores) unless MRT_PNG_THREADS says otherwise:
+    // a caller who has the whole node (the frame of eight GPUs) can give the encoder more.
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned cap = 16u;
+    if (const char* env = std::getenv("MRT_PNG_THREADS")) {
+        const long v = std::strtol(env, nullptr, 10);
+        if (v >= 1 && v <= 1024) cap = static_cast<unsigned>(v);
+    }
+    const unsigned n_threads = std::max(1u, std::min<unsigned>(std::min(hw ? hw : 1u, cap), n_stripes));
+    for (unsigned t = 0; t < n_threads; ++t) s->pool.emplace_back(stream_worker, s);
+    *out = s;
+    return MRT_OK;
+}
+
+extern "C" int mrt_png_stream_rows(mrt_png_stream* s, uint32_t row_begin, uint32_t row_end) {
+    if (!s || row_begin > row_end || row_end > s->yres) return MRT_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(s->mu);
+    for (uint32_t r = row_begin; r < row_end;) {
+        const uint32_t k = r / s->rows_per;
+        const uint32_t upto = std::min(row_end, s->stripes[k].row_end);
+        s->rows_in[k] += upto - r;
+        const uint32_t rows = s->stripes[k].row_end - s->stripes[k].row_begin;
+        if (s->rows_in[k] > rows) return MRT_ERR_INVALID;                   // a row reported twice
+        if (s->rows_in[k] == rows) {
+            s->runnable.push_back(k);
+            s->cv_work.notify_one();
+        }
+        r = upto;
+    }
+    return MRT_OK;
+}
+
+extern "C" int mrt_png_stream_end(mrt_png_stream* s) {
+    if (!s) return MRT_ERR_INVALID;
+    int rc = MRT_OK;
+    {
+        std::unique_lock<std::mutex> lock(s->mu);
+        uint32_t started = 0;
+        for (size_t k = 0; k < s->stripes.size(); ++k)
+            started += s->rows_in[k] == s->stripes[k].row_end - s->stripes[k].row_begin ? 1u : 0u;
+        if (started != s->stripes.size()) rc = MRT_ERR_INVALID;             // rows were never reported: no file
+        s->cv_done.wait(lock, [&] { return s->done == started; });
+        s->closing = true;
+        s->cv_work.notify_all();
+    }
+    for (auto& th : s->pool) th.join();
+    if (rc == MRT_OK)
+        for (const auto& st : s->stripes)
+            if (!st.ok) rc = MRT_ERR_IO;
+    if (rc == MRT_OK && !write_file(*s)) rc = MRT_ERR_IO;
+    delete s;
+    return rc;
+}
+
+extern "C" int mrt_write_png_rgb(const char* path, const uint8_t* rgba, uint32_t xres, uint32_t yres) {
+    mrt_png_stream* s = nullptr;
+    int rc = mrt_png_stream_begin(path, rgba, xres, yres, &s);
+    if (rc != MRT_OK) return rc;
+    rc = mrt_png_stream_rows(s, 0, yres);
+    const int rc_end = mrt_png_stream_end(s);
+    return rc != MRT_OK ? rc : rc_end;
 }

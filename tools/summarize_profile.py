@@ -2,7 +2,10 @@
 are committed under profiles/<round>/: the rocprofv3 kernel-stats CSV as is, plus the mean per
 launch of every hardware counter for the render kernels (CSV and JSON).
 
-Usage: python tools/summarize_profile.py gpurun_out/prof_r1b profiles/r1
+Usage: python tools/summarize_profile.py gpurun_out/prof_r1b profiles/r1 [name]
+name (default teatime4k) prefixes the files written: the same layout comes out of tools/profile.sh
+(the 4K benchmark command), tools/profile_stages.sh (name stage_intersect) and, per frame, of
+tools/profile_frames.sh (names soup16k, teatime8k).
 """
 import collections
 import csv
@@ -12,10 +15,10 @@ import sys
 from pathlib import Path
 
 
-def main(src, dst):
+def main(src, dst, name="teatime4k"):
     src, dst = Path(src), Path(dst)
     dst.mkdir(parents=True, exist_ok=True)
-    shutil.copy(src / "trace" / "trace_kernel_stats.csv", dst / "teatime4k_kernel_stats.csv")
+    shutil.copy(src / "trace" / "trace_kernel_stats.csv", dst / f"{name}_kernel_stats.csv")
     accel = src / "trace_accel" / "trace_kernel_stats.csv"
     if accel.is_file():            # tools/time_accel.py teatime4k soup16k: the mrt_accel_* kernels
         shutil.copy(accel, dst / "accel_kernel_stats.csv")
@@ -38,19 +41,19 @@ def main(src, dst):
         for (k, c), v in sorted(agg.items()):
             e = out.setdefault(k, {"dispatch": meta[k], "counters_mean_per_launch": {}, "launches": len(v)})
             e["counters_mean_per_launch"][c] = sum(v) / len(v)
-    (dst / "teatime4k_pmc_summary.json").write_text(json.dumps(out, indent=1))
-    with open(dst / "teatime4k_pmc_summary.csv", "w") as f:
+    (dst / f"{name}_pmc_summary.json").write_text(json.dumps(out, indent=1))
+    with open(dst / f"{name}_pmc_summary.csv", "w") as f:
         f.write("kernel,counter,mean_per_launch\n")
         for k, d in out.items():
             for c, v in d["counters_mean_per_launch"].items():
                 f.write(f"\"{k}\",{c},{v:.6g}\n")
-    print((dst / "teatime4k_kernel_stats.csv").read_text())
+    print((dst / f"{name}_kernel_stats.csv").read_text())
     for k, d in out.items():
-        if "trace_kernel" in k:
+        if "trace_kernel" in k or "general_intersect" in k:
             print(k, d["dispatch"])
             for c, v in d["counters_mean_per_launch"].items():
                 print(f"  {c:28s} {v:.6g}")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:4])
