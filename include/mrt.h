@@ -211,7 +211,9 @@ int mrt_render_rgba8(mrt_ctx *ctx, uint8_t *host_out, mrt_stats *stats /* may be
 
 /* mrt_render_rgba8 for a caller who can use the rows as they arrive (an encoder,
  * a display): the frame is rendered in strips of strip_rows consecutive rows
- * (0 = the library's choice, about eight per frame), every strip is copied to
+ * (0 = the library's choice: about eight for a frame of 2^40 ray-primitive pairs
+ * and more, one below, where the kernels are over before there is anything to
+ * hide behind them), every strip is copied to
  * host_out behind its kernels and beside the strips that follow, and
  * ready(user, row_begin, row_end) is called -- on the calling thread, in row
  * order -- as soon as rows [row_begin, row_end) of host_out are final.  Same

@@ -35,7 +35,8 @@ EXPORTED_SYMBOLS = [
     "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_abi_version", "mrt_set_scene", "mrt_set_camera",
     "mrt_render_rgba8", "mrt_render_debug", "mrt_band_rows", "mrt_balanced_band_rows", "mrt_render_bands_device",
     "mrt_bands_to_image", "mrt_scene_load_file", "mrt_scene_load_text", "mrt_scene_view",
-    "mrt_scene_info_view", "mrt_scene_free", "mrt_write_png_rgb", "mrt_stage_uv",
+    "mrt_scene_info_view", "mrt_scene_free", "mrt_write_png_rgb", "mrt_png_stream_begin", "mrt_png_stream_rows",
+    "mrt_png_stream_end", "mrt_render_rgba8_rows", "mrt_multi_render_rgba8_rows", "mrt_stage_uv",
     "mrt_stage_ortho_viewrays", "mrt_stage_persp_viewrays", "mrt_stage_intersect",
     "mrt_stage_flat_shader", "mrt_stage_phong_shader", "mrt_stage_last_kernel_ms", "mrt_synchronize", "mrt_host_alloc", "mrt_host_free",
     "mrt_render_bands_device_noalloc",
@@ -180,6 +181,9 @@ class MrtError(RuntimeError):
         self.message = message
 
 
+ROWS_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)      # mrt_rows_ready_fn
+
+
 def lib_path() -> Path:
     return Path(os.environ.get("MRT_HIP_LIB", PKG_DIR / "libmrt_hip.so"))
 
@@ -277,6 +281,11 @@ def lib():
     L.mrt_scene_free.argtypes = [vp]
     L.mrt_scene_free.restype = None
     L.mrt_write_png_rgb.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+    L.mrt_png_stream_begin.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.mrt_png_stream_rows.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.mrt_png_stream_end.argtypes = [vp]
+    L.mrt_render_rgba8_rows.argtypes = [vp, vp, C.c_uint32, ROWS_READY_FN, vp, C.POINTER(Stats)]
+    L.mrt_multi_render_rgba8_rows.argtypes = [vp, vp, ROWS_READY_FN, vp, C.POINTER(MultiStats)]
     L.mrt_stage_uv.argtypes = [vp, vp, vp, C.c_int, vp]
     L.mrt_stage_ortho_viewrays.argtypes = [vp, vp, vp, C.c_int, vp]
     L.mrt_stage_persp_viewrays.argtypes = [vp, vp, vp, C.c_int, C.c_float, vp]
@@ -454,6 +463,16 @@ class Context:
         self._check(lib().mrt_render_debug(self._h, img.ctypes.data, ids.ctypes.data, t.ctypes.data,
                                            C.byref(stats)))
         return img, ids, t, stats
+
+    def render_rows(self, out, on_rows=None, strip_rows=0):
+        """mrt_render_rgba8_rows: the frame into `out` strip by strip; on_rows(row_begin, row_end) is
+        called as rows become final.  Returns stats."""
+        stats = Stats()
+        if out.shape != (self.yres, self.xres, 4) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of shape (yres, xres, 4)")
+        cb = ROWS_READY_FN((lambda user, a, b: on_rows(a, b)) if on_rows else (lambda user, a, b: None))
+        self._check(lib().mrt_render_rgba8_rows(self._h, out.ctypes.data, strip_rows, cb, None, C.byref(stats)))
+        return stats
 
     def render_bands_device(self, band_rows_, rank, world, dev_ptr, nbytes, stream=0, timed=False):
         stats = Stats() if timed else None
@@ -642,6 +661,15 @@ class MultiContext:
         self._check(lib().mrt_multi_render_rgba8(self._h, img.ctypes.data, C.byref(stats)))
         return img, stats
 
+    def render_rows(self, out, on_rows=None):
+        """mrt_multi_render_rgba8_rows: on_rows(row_begin, row_end) per band as it lands in `out`."""
+        stats = MultiStats()
+        if out.shape != (self.yres, self.xres, 4) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array of shape (yres, xres, 4)")
+        cb = ROWS_READY_FN((lambda user, a, b: on_rows(a, b)) if on_rows else (lambda user, a, b: None))
+        self._check(lib().mrt_multi_render_rgba8_rows(self._h, out.ctypes.data, cb, None, C.byref(stats)))
+        return stats
+
     def close(self):
         if self._h:
             lib().mrt_multi_destroy(self._h)
@@ -770,3 +798,27 @@ def write_png_rgb(path, rgba: np.ndarray):
     rc = lib().mrt_write_png_rgb(str(path).encode(), a.ctypes.data, a.shape[1], a.shape[0])
     if rc != 0:
         raise MrtError(rc, "mrt_write_png_rgb")
+
+
+class PngStream:
+    """mrt_png_stream: a PNG encoded while its rows arrive in `rgba` (kept alive by this object)."""
+
+    def __init__(self, path, rgba: np.ndarray):
+        if rgba.dtype != np.uint8 or rgba.ndim != 3 or rgba.shape[2] != 4 or not rgba.flags.c_contiguous:
+            raise ValueError("rgba must be a C-contiguous uint8 array of shape (yres, xres, 4)")
+        self._rgba = rgba
+        self._h = C.c_void_p()
+        rc = lib().mrt_png_stream_begin(str(path).encode(), rgba.ctypes.data, rgba.shape[1], rgba.shape[0], C.byref(self._h))
+        if rc != 0:
+            raise MrtError(rc, "mrt_png_stream_begin")
+
+    def rows(self, row_begin, row_end):
+        rc = lib().mrt_png_stream_rows(self._h, row_begin, row_end)
+        if rc != 0:
+            raise MrtError(rc, "mrt_png_stream_rows")
+
+    def end(self):
+        h, self._h = self._h, None
+        rc = lib().mrt_png_stream_end(h)
+        if rc != 0:
+            raise MrtError(rc, "mrt_png_stream_end")

@@ -1023,13 +1023,20 @@ int mrt_render_rgba8_rows(mrt_ctx* ctx, uint8_t* host_out, uint32_t strip_rows, 
     const uint32_t xres = ctx->params.xres, yres = ctx->params.yres;
     const size_t npx = (size_t)xres * yres;
     if (strip_rows == 0) {
-        // about eight strips, whole block tiles each; a small frame is one strip
-        strip_rows = npx < (2u << 20) ? yres : round_up((yres + 7) / 8, 64);
+        // Strips pay when the kernels run long enough to hide something behind them -- from about
+        // 2^40 ray-primitive pairs (the 16384^2 soup has 2^42; a 3840x2160 frame of the teatime mesh,
+        // 2^35, renders in a millisecond and loses more to seven small launches than its copy costs):
+        // about eight strips then, whole block tiles each; one strip otherwise.
+        const unsigned long long pairs = (unsigned long long)npx * ((unsigned long long)ctx->params.n_sph + ctx->params.n_tri);
+        strip_rows = pairs < (1ull << 40) ? yres : round_up((yres + 7) / 8, 64);
     }
     const uint32_t n_strips = (yres + strip_rows - 1) / strip_rows;
     int rc = ensure_out(ctx, npx);
     if (rc != MRT_OK) return rc;
-    if (!ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    // (a frame in one strip is copied on the ctx's own stream: a second stream costs a hardware
+    // queue, milliseconds the first time, and has nothing to overlap)
+    if (n_strips > 1 && !ctx->copy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    hipStream_t copy_stream = n_strips > 1 ? ctx->copy_stream : ctx->stream;
     while (ctx->strip_events.size() < 2 * (size_t)n_strips) {
         hipEvent_t e = nullptr;
         HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1038,28 +1045,33 @@ int mrt_render_rgba8_rows(mrt_ctx* ctx, uint8_t* host_out, uint32_t strip_rows, 
     // Every strip is a frame of its own on the ctx's stream (band k of n_strips bands of strip_rows
     // rows belongs to "rank" k); its copy to the host runs on the copy stream, beside the strips
     // that follow, and the caller hears of it as soon as it has landed.
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (n_strips > 1) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));    // (one strip: launch_frame times itself)
     for (uint32_t k = 0; k < n_strips; ++k) {
         const size_t off = (size_t)k * strip_rows * xres;
         const uint32_t rows = mrt_band_rows(yres, strip_rows, k, n_strips);
-        rc = launch_frame(ctx, strip_rows, k, n_strips, ctx->d_out + off, ctx->stream, false, FramePlanes{});
+        rc = launch_frame(ctx, strip_rows, k, n_strips, ctx->d_out + off, ctx->stream, n_strips == 1, FramePlanes{});
         if (rc != MRT_OK) break;
         hipEvent_t rendered = ctx->strip_events[2 * k], copied = ctx->strip_events[2 * k + 1];
-        hipError_t e = hipEventRecord(rendered, ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, rendered, 0);
+        hipError_t e = hipSuccess;
+        if (copy_stream != ctx->stream) {
+            e = hipEventRecord(rendered, ctx->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(copy_stream, rendered, 0);
+        }
         if (e == hipSuccess)
-            e = hipMemcpyAsync(host_out + off * 4, ctx->d_out + off, (size_t)rows * xres * 4, hipMemcpyDeviceToHost, ctx->copy_stream);
-        if (e == hipSuccess) e = hipEventRecord(copied, ctx->copy_stream);
+            e = hipMemcpyAsync(host_out + off * 4, ctx->d_out + off, (size_t)rows * xres * 4, hipMemcpyDeviceToHost, copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(copied, copy_stream);
         if (e != hipSuccess) { rc = fail(ctx, MRT_ERR_HIP, std::string("strip copy: ") + hipGetErrorString(e)); break; }
     }
     if (rc != MRT_OK) {
         // nothing may still be writing host_out when the caller sees the error
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamSynchronize(ctx->copy_stream);
+        if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
         return rc;
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (n_strips > 1) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    }
     for (uint32_t k = 0; k < n_strips; ++k) {
         HIP_TRY(ctx, hipEventSynchronize(ctx->strip_events[2 * k + 1]));
         const uint32_t r0 = k * strip_rows;

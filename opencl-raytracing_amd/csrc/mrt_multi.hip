@@ -78,6 +78,12 @@ struct Rank {
     ncclComm_t comm = nullptr;
 };
 
+// The event behind the copy of one band to the host, and the GPU it lives on.
+struct BandEvent {
+    hipEvent_t event = nullptr;
+    int device = 0;
+};
+
 }  // namespace
 
 struct mrt_multi {
@@ -173,6 +179,8 @@ void mrt_multi_destroy(mrt_multi* m) {
     }
     for (Rank& r : m->ranks)
         if (r.comm) { (void)hipSetDevice(r.device); (void)rccl().comm_destroy(r.comm); r.comm = nullptr; }
+    for (BandEvent& be : m->band_events)
+        if (be.event) { (void)hipSetDevice(be.device); (void)hipEventDestroy(be.event); }
     if (!m->ranks.empty()) release_buffers(m);
     for (Rank& r : m->ranks) {
         (void)hipSetDevice(r.device);

@@ -208,12 +208,17 @@ extern "C" int mrt_png_stream_begin(const char* path, const uint8_t* rgba, uint3
 extern "C" int mrt_png_stream_rows(mrt_png_stream* s, uint32_t row_begin, uint32_t row_end) {
     if (!s || row_begin > row_end || row_end > s->yres) return MRT_ERR_INVALID;
     std::lock_guard<std::mutex> lock(s->mu);
+    for (uint32_t r = row_begin; r < row_end;) {                            // a row reported twice: nothing is taken
+        const uint32_t k = r / s->rows_per;
+        const uint32_t upto = std::min(row_end, s->stripes[k].row_end);
+        if (s->rows_in[k] + (upto - r) > s->stripes[k].row_end - s->stripes[k].row_begin) return MRT_ERR_INVALID;
+        r = upto;
+    }
     for (uint32_t r = row_begin; r < row_end;) {
         const uint32_t k = r / s->rows_per;
         const uint32_t upto = std::min(row_end, s->stripes[k].row_end);
         s->rows_in[k] += upto - r;
         const uint32_t rows = s->stripes[k].row_end - s->stripes[k].row_begin;
-        if (s->rows_in[k] > rows) return MRT_ERR_INVALID;                   // a row reported twice
         if (s->rows_in[k] == rows) {
             s->runnable.push_back(k);
             s->cv_work.notify_one();

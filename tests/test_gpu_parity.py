@@ -1011,3 +1011,54 @@ def test_dist_cli_two_ranks_on_one_gpu(tmp_path):
     r = subprocess.run([sys.executable, str(script), str(bad), str(out)], capture_output=True, text=True, env=env,
                        timeout=120)
     assert r.returncode == 1 and "rayson must be comprised of one JSON object" in r.stderr
+
+
+def test_frames_that_arrive_row_by_row(gpu_ctx, mrt):
+    """mrt_render_rgba8_rows and mrt_multi_render_rgba8_rows: the bytes of mrt_render_rgba8, the
+    callback covering every row exactly once, in order, and only rows that are already final in the
+    caller's buffer; fed to mrt_png_stream_* they give the PNG mrt_write_png_rgb writes."""
+    import tempfile
+    from pathlib import Path
+    for text, strips in ((mkscene.teatime(1920, 1080), (0, 64, 100, 5000)), (mkscene.soup(2048, 2048), (0, 256)),
+                         (mkscene.teatime(640, 360), (0, 7))):
+        sc = mrt.LoadedScene(text=text).copy()
+        gpu_ctx.set_scene(sc)
+        want, _ = gpu_ctx.render()
+        for strip in strips:
+            out = mrt.host_array(want.shape)
+            out[:] = 0x5A
+            seen = []
+
+            def on_rows(a, b):
+                assert np.array_equal(out[a:b], want[a:b])           # final when reported
+                seen.append((a, b))
+
+            st = gpu_ctx.render_rows(out, on_rows, strip_rows=strip)
+            assert np.array_equal(out, want), strip
+            assert seen[0][0] == 0 and seen[-1][1] == want.shape[0]
+            assert all(x[1] == y[0] for x, y in zip(seen, seen[1:])) and st.rays == want.shape[0] * want.shape[1]
+            if strip == 64:
+                assert len(seen) == (want.shape[0] + 63) // 64
+        for gather in (mrt.GATHER_PEER, mrt.GATHER_HOST):
+            m = mrt.MultiContext(devices=[0, 0, 0], gather=gather)
+            try:
+                m.set_scene(sc)
+                out = mrt.host_array(want.shape)
+                out[:] = 0
+                seen = []
+                with tempfile.TemporaryDirectory() as d:
+                    png = mrt.PngStream(Path(d) / "s.png", out)
+
+                    def on_band(a, b):
+                        assert np.array_equal(out[a:b], want[a:b])
+                        seen.append((a, b))
+                        png.rows(a, b)
+
+                    m.render_rows(out, on_band)
+                    png.end()
+                    mrt.write_png_rgb(Path(d) / "p.png", want)
+                    assert (Path(d) / "s.png").read_bytes() == (Path(d) / "p.png").read_bytes()
+                assert np.array_equal(out, want)
+                assert seen[0][0] == 0 and seen[-1][1] == want.shape[0] and all(x[1] == y[0] for x, y in zip(seen, seen[1:]))
+            finally:
+                m.close()

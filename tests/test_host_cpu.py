@@ -264,3 +264,36 @@ def test_committed_profile_feeds_the_bench_line():
     assert 1.5 < default["SQ_INSTS_VALU"] * 64 / pairs < 3.0
     assert default["SQ_WAVES"] == 130560                                # a context's 4K frame in 32 slices
     assert bench.algorithmic_flops(type("S", (), {"n_tris": 4032, "n_spheres": 2}), 3840 * 2160) == 1505267712000.0
+
+
+def test_png_stream_writes_the_same_file(mrt, tmp_path):
+    """mrt_png_stream_*: rows reported in pieces and out of order give the file mrt_write_png_rgb
+    writes, byte for byte; a stream whose rows never all arrive writes nothing and says so."""
+    rng = np.random.default_rng(3)
+    for h, w in ((1, 1), (37, 53), (700, 2048), (3000, 900)):        # one stripe, several, many
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        img[h // 3:2 * h // 3 + 1] = 77                               # something deflate can compress
+        plain, streamed = tmp_path / "plain.png", tmp_path / "streamed.png"
+        mrt.write_png_rgb(plain, img)
+        s = mrt.PngStream(streamed, img)
+        cuts = sorted({0, h} | set(int(x) for x in rng.integers(0, h + 1, 7)))
+        spans = list(zip(cuts, cuts[1:]))
+        for k in rng.permutation(len(spans)):
+            s.rows(*spans[k])
+        s.end()
+        assert streamed.read_bytes() == plain.read_bytes(), (h, w)
+        from PIL import Image
+        assert np.array_equal(np.asarray(Image.open(streamed)), img[..., :3])
+    missing = tmp_path / "missing.png"
+    s = mrt.PngStream(missing, img)
+    s.rows(0, h - 1)
+    with pytest.raises(mrt.MrtError):
+        s.end()
+    assert not missing.exists()
+    s = mrt.PngStream(missing, img)
+    s.rows(0, h)
+    with pytest.raises(mrt.MrtError):
+        s.rows(5, 6)                                                  # a row reported twice
+    with pytest.raises(mrt.MrtError):
+        s.rows(0, h + 1)
+    s.end()
