@@ -155,8 +155,10 @@ class Job:
             self.seq.set_scene(scene)
         self.slot_streams = [env.stream] if in_flight == 1 else [None] * in_flight
         mrt, world = env.mrt, env.world
-        self.rows = mrt.band_rows(st.yres, BAND_ROWS, env.rank, world)
-        nbytes = max(mrt.band_rows(st.yres, BAND_ROWS, r, world) for r in range(world)) * st.xres * 4
+        # 64 rows per band, or 32 when that leaves the busiest rank fewer rows (7680x4320 over 8 ranks)
+        self.band = mrt.balanced_band_rows(st.yres, world) if world > 1 else BAND_ROWS
+        self.rows = mrt.band_rows(st.yres, self.band, env.rank, world)
+        nbytes = max(mrt.band_rows(st.yres, self.band, r, world) for r in range(world)) * st.xres * 4
         # two buffer sets per frame in flight: the gather of a frame overlaps the next frame of its slot
         self.n_sets = 2 * in_flight
         self.local = [torch.empty(nbytes, dtype=torch.uint8, device=env.dev) for _ in range(self.n_sets)]
@@ -174,10 +176,10 @@ class Job:
                 self.works[b].wait()
             self.works[b] = None
         if self.seq is None:
-            self.ctx.render_bands_device(BAND_ROWS, env.rank, env.world, self.local[b].data_ptr(),
+            self.ctx.render_bands_device(self.band, env.rank, env.world, self.local[b].data_ptr(),
                                          self.local[b].numel(), stream=env.stream.cuda_stream)
         else:
-            ptr = self.seq.submit(BAND_ROWS, env.rank, env.world, self.local[b].data_ptr(), self.local[b].numel())
+            ptr = self.seq.submit(self.band, env.rank, env.world, self.local[b].data_ptr(), self.local[b].numel())
             if self.slot_streams[f] is None:
                 self.slot_streams[f] = torch.cuda.ExternalStream(ptr, device=env.dev)
         if env.use_dist:
@@ -224,10 +226,10 @@ class Job:
         not after an idle gap."""
         tr, sh = [], []
         for _ in range(reps):
-            self.ctx.render_bands_device(BAND_ROWS, self.env.rank, self.env.world,
+            self.ctx.render_bands_device(self.band, self.env.rank, self.env.world,
                                          self.local[1].data_ptr(), self.local[1].numel(),
                                          stream=self.env.stream.cuda_stream)
-            s = self.ctx.render_bands_device(BAND_ROWS, self.env.rank, self.env.world,
+            s = self.ctx.render_bands_device(self.band, self.env.rank, self.env.world,
                                              self.local[0].data_ptr(), self.local[0].numel(),
                                              stream=self.env.stream.cuda_stream, timed=True)
             tr.append(s.trace_ms)
@@ -252,7 +254,7 @@ def secondary_workloads(env, mkscene):
         tr, sh = job.kernel_ms(kernel_reps)
         rays = st.xres * st.yres
         n_prims = st.n_spheres + st.n_tris
-        e = {"xres": st.xres, "yres": st.yres, "n_gpus": env.world, "primitives": n_prims,
+        e = {"xres": st.xres, "yres": st.yres, "n_gpus": env.world, "primitives": n_prims, "band_rows": job.band,
              "frames_in_flight": job.in_flight,
              "ms_per_frame": elapsed / steps * 1e3, "mrays_per_s": rays * steps / elapsed * 1e-6,
              "prim_tests_per_s": rays * n_prims * steps / elapsed,
@@ -266,7 +268,7 @@ def secondary_workloads(env, mkscene):
         """Grid statistics of an mrt_accel job (build time per view, cells, references)."""
         if not isinstance(job.ctx, mrt.Accel) or job.ctx.method != mrt.ACCEL_GRID:
             return None
-        s = job.ctx.render_bands_device(BAND_ROWS, env.rank, env.world, job.local[0].data_ptr(),
+        s = job.ctx.render_bands_device(job.band, env.rank, env.world, job.local[0].data_ptr(),
                                         job.local[0].numel(), stream=env.stream.cuda_stream, timed=True)
         return {"grid_build_ms_per_view": s.build_ms, "grid_cells": s.cells, "grid_refs": s.refs}
 
@@ -602,9 +604,9 @@ def main():
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "teatime_4k" if world == 1 else f"teatime_3840x{st.yres}_bands{BAND_ROWS}",
+            "config": {"workload": "teatime_4k" if world == 1 else f"teatime_3840x{st.yres}_bands{job.band}",
                        "xres": st.xres, "yres": st.yres, "rays_per_step": total_rays,
-                       "primitives": n_prims, "band_rows": BAND_ROWS, "frames_in_flight": FRAMES_IN_FLIGHT,
+                       "primitives": n_prims, "band_rows": job.band, "frames_in_flight": FRAMES_IN_FLIGHT,
                        "gather": ("none" if not env.use_dist else
                                   "REHEARSAL: all ranks on GPU 0, gloo gather through host memory"
                                   if env.rehearsal else "rccl gather to rank 0, overlapped with the next frame"),
