@@ -42,7 +42,9 @@ teatime8k_* keys, among them *_one_gpu_ms_per_frame (the same frame on rank 0's 
 in the same run) and *_speedup_vs_one_gpu.  With N = 1 the compute side of that scaling curve is
 bounded on the one GPU: *_rank_alone_ms_w{2,4,8} is the device time of the slower of ranks 0 and
 w - 1 rendering its interleaved bands of the frame alone, *_compute_eff_w{2,4,8} = T(whole frame)
-/ (w * that) -- the efficiency w GPUs would reach if the gather cost nothing.
+/ (w * that) -- the efficiency w GPUs would reach if the gather cost nothing
+(*_compute_eff_two_in_flight_w*: the same with two frames in flight on either side, which is how
+these jobs run).
 """
 import argparse
 import json
@@ -300,6 +302,7 @@ def secondary_workloads(env, mkscene):
             res[name][f"rank_alone_ms_w{w}"] = b[f"w{w}"]["rank_alone_ms"]
             res[name][f"compute_eff_w{w}"] = b[f"w{w}"]["compute_eff"]
             res[name][f"compute_eff_back_to_back_w{w}"] = b[f"w{w}"]["compute_eff_back_to_back"]
+            res[name][f"compute_eff_two_in_flight_w{w}"] = b[f"w{w}"]["compute_eff_two_in_flight"]
         res[name]["rank_alone"] = b
 
     # The 16384 x 16384 triangle soup, one frame split over all ranks (strong scaling).
