@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -608,8 +609,17 @@ int mrt_create(const mrt_config* cfg, mrt_ctx** out) {
 int mrt_create_internal_(const mrt_config* cfg, mrt_ctx** out) {
     if (!out) return fail(nullptr, MRT_ERR_INVALID, "out is NULL");
     *out = nullptr;
+    // MRT_STATS=1: where the start-up of the first context of a process goes, one JSON line on stderr
+    using clk = std::chrono::steady_clock;
+    const char* want_stats = std::getenv("MRT_STATS");
+    static bool first_context = true;                  // (the start-up is the first context's; later ones find it done)
+    const bool stats = want_stats && want_stats[0] == '1' && first_context;
+    first_context = false;
+    const auto t0 = clk::now();
+    auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
+    const double runtime_ms = ms_since(t0);            // the HIP runtime starts up here
     if (e != hipSuccess || count <= 0)
         return fail(nullptr, MRT_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
     int dev = cfg ? cfg->device : -1;
@@ -632,13 +642,23 @@ int mrt_create_internal_(const mrt_config* cfg, mrt_ctx** out) {
     };
     DeviceGuard guard(dev);
     if (guard.err != hipSuccess) return bail("hipSetDevice", guard.err);
+    const auto t1 = clk::now();
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    const double stream_ms = ms_since(t1);             // the device is opened, a hardware queue made
     for (int k = 0; k < 3; ++k)
         if ((e = hipEventCreate(&ctx->ev[k])) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->frame_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->records_ready, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    const auto t2 = clk::now();
     if ((e = hipMalloc((void**)&ctx->d_counter, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    const double malloc_ms = ms_since(t2);
+    const auto t3 = clk::now();
     if ((e = scratch_address(dev, &ctx->scratch_keys)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
+    const double code_object_ms = ms_since(t3);        // the library's code object is loaded onto the GPU, its 64 MiB array with it
+    if (stats)
+        std::fprintf(stderr, "{\"mrt_create\": {\"runtime_start_ms\": %.3f, \"first_stream_ms\": %.3f, \"first_malloc_ms\": %.3f, "
+                             "\"code_object_load_ms\": %.3f, \"total_ms\": %.3f}}\n",
+                     runtime_ms, stream_ms, malloc_ms, code_object_ms, ms_since(t0));
     *out = ctx;
     return MRT_OK;
 }

@@ -129,13 +129,15 @@ __device__ __forceinline__ bool is_wild(float4 ro, float4 rd) {
 
 // Per component, the largest |origin| and |direction| over the rays that are not wild, as the
 // bit patterns of non-negative floats under atomicMax (bounds[0..2] origin, [3..5] direction):
-// four rays per thread, one set of atomics per block.
+// four rays per thread, one set of atomics per block.  Also sets every ray's key to "no hit".
 __global__ __launch_bounds__(256) void general_ray_bounds(const float4* __restrict__ rays, int n_rays,
-                                                          uint32_t* __restrict__ bounds) {
+                                                          uint32_t* __restrict__ bounds,
+                                                          unsigned long long* __restrict__ keys) {
     __shared__ float s_m[4][6];
     float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rays; i += gridDim.x * blockDim.x) {
         const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
+        keys[i] = ~0ull;
         if (is_wild(ro, rd)) continue;
         m[0] = fmaxf(m[0], fabsf(ro.x)); m[1] = fmaxf(m[1], fabsf(ro.y)); m[2] = fmaxf(m[2], fabsf(ro.z));
         m[3] = fmaxf(m[3], fabsf(rd.x)); m[4] = fmaxf(m[4], fabsf(rd.y)); m[5] = fmaxf(m[5], fabsf(rd.z));
@@ -734,11 +736,10 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
 
     hipEvent_t ev0 = (hipEvent_t)mrt_stage_event_(ctx, 0), ev1 = (hipEvent_t)mrt_stage_event_(ctx, 1);
     STAGE_TRY(hipEventRecord(ev0, stage_stream));
-    STAGE_TRY(hipMemsetAsync(d_keys.p, 0xFF, (size_t)n_rays * sizeof(unsigned long long), stage_stream));
     {
         const int blocks = (n_rays + 1023) / 1024;
         hipLaunchKernelGGL(mrt::general_ray_bounds, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stage_stream,
-                           (const float4*)d_rays.p, n_rays, d_bounds);
+                           (const float4*)d_rays.p, n_rays, d_bounds, (unsigned long long*)d_keys.p);
         STAGE_TRY(hipGetLastError());
     }
     if (n_tri) {
