@@ -435,6 +435,24 @@ def general_ray(env, reps=12):
             ctx.stage_intersect(objs, rays, flt_max, 0.0)
             if k >= 2:
                 ms.append(ctx.stage_kernel_ms())
+        # ... and on the benchmark frame's own rays: 3840 x 2160 of them as an array (265 MB in, 663 MB
+        # of hit records out: the call takes a second, its kernels are what is timed)
+        import mkscene
+        from test_gpu_stages import frame_rays
+        big_rays, big_objs = frame_rays(mrt, ctx, mrt.LoadedScene(text=mkscene.teatime(XRES, YRES)).copy())
+        big_ms = []
+        for k in range(3):
+            ctx.stage_intersect(big_objs, big_rays, flt_max, 0.0)
+            big_ms.append(ctx.stage_kernel_ms())
+        big_ms.sort()
+        big = {"rays": len(big_rays), "objects": len(big_objs), "kernel_ms": big_ms[1],
+               "mrays_per_s": len(big_rays) / big_ms[1] * 1e-3,
+               "prim_tests_per_s": len(big_rays) * len(big_objs) / (big_ms[1] * 1e-3)}
+        big["achieved"] = len(big_rays) * (int(big_objs["is_triangle"].sum()) * FLOPS_PER_TRI_TEST +
+                                           int((big_objs["is_triangle"] == 0).sum()) * FLOPS_PER_SPH_TEST) / (big_ms[1] * 1e-3) * 1e-12
+        big["frac"] = big["achieved"] / FP32_PEAK_TFLOPS
+        big["frac_executed"] = big["frac"] * GENERAL_RAY_EXECUTED_FLOPS / FLOPS_PER_TRI_TEST
+        del big_rays
     finally:
         ctx.close()
     ms.sort()
@@ -452,6 +470,7 @@ def general_ray(env, reps=12):
             "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
             "executed_flops_per_pair": GENERAL_RAY_EXECUTED_FLOPS,
             "frac_executed": achieved / FP32_PEAK_TFLOPS * GENERAL_RAY_EXECUTED_FLOPS / FLOPS_PER_TRI_TEST,
+            "teatime_4k_rays": big,
             "note": "arbitrary rays: origin and direction per ray from memory, caller's t range, objects in any order; "
                     "per pair six dot products of the ray's (direction, moment, origin) with per-triangle vectors (the "
                     "four determinants of tri_intersect's Cramer solve) as a conservative filter, the reference's unfused "

@@ -62,6 +62,25 @@ def make_inputs(mrt, sc, n_side):
     return pos, vp, cam, objs, lights, phong
 
 
+def frame_rays(mrt, ctx, sc):
+    """The primary rays of scene `sc`'s frame (xres x yres, its viewport and camera) as the array of
+    rays the stage entry points pass around, made by the uv and view-ray stages on the GPU, and the
+    scene's objects in the reference's records."""
+    st = sc.struct
+    D = mrt.CL_DTYPES
+    n = st.xres * st.yres
+    i = np.arange(n)
+    pos = np.zeros(n, D["float3"])
+    pos["s"][:, 0] = (i % st.xres) + 1.0
+    pos["s"][:, 1] = (i // st.xres) + 1.0
+    vp = np.zeros(1, D["vp"])
+    vp["x_resolution"], vp["y_resolution"] = st.xres, st.yres
+    vp["left"], vp["right"], vp["top"], vp["bottom"] = st.left, st.right, st.top, st.bottom
+    _, _, cam, objs, _, _ = make_inputs(mrt, sc, 2)
+    focal = None if st.projection == mrt.PROJ_ORTHO else st.focal
+    return ctx.stage_viewrays(cam, ctx.stage_uv(pos, vp), focal), objs
+
+
 @pytest.mark.parametrize("name,n_side", [("scene_2spheres_persp_phong", 150), ("scene_gtri_ortho_phong", 150),
                                          ("teatime", 96)])
 def test_stage_pipeline_matches_oracle(gpu_ctx, mrt, oracle, name, n_side):
@@ -321,17 +340,8 @@ def test_stage_intersect_equals_the_fused_path_on_a_frame(gpu_ctx, mrt):
     st = sc.struct
     gpu_ctx.set_scene(sc)
     _, ids, t, _ = gpu_ctx.render(want_ids=True)
-    D = mrt.CL_DTYPES
     n = st.xres * st.yres
-    i = np.arange(n)
-    pos = np.zeros(n, D["float3"])
-    pos["s"][:, 0] = (i % st.xres) + 1.0
-    pos["s"][:, 1] = (i // st.xres) + 1.0
-    vp = np.zeros(1, D["vp"])
-    vp["x_resolution"], vp["y_resolution"] = st.xres, st.yres
-    vp["left"], vp["right"], vp["top"], vp["bottom"] = st.left, st.right, st.top, st.bottom
-    _, _, cam, objs, _, _ = make_inputs(mrt, sc, 2)
-    rays = gpu_ctx.stage_viewrays(cam, gpu_ctx.stage_uv(pos, vp), st.focal)
+    rays, objs = frame_rays(mrt, gpu_ctx, sc)
     xs = gpu_ctx.stage_intersect(objs, rays, float(np.finfo(np.float32).max), 0.0)
     ms = gpu_ctx.stage_kernel_ms()
     hit = xs["intersects"].reshape(st.yres, st.xres) != 0
