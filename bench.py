@@ -708,7 +708,7 @@ def main():
                         out[f"{key}_one_gpu_ms_per_frame"] = sec[name]["one_gpu_ms_per_frame"]
                         out[f"{key}_speedup_vs_one_gpu"] = sec[name]["speedup_vs_one_gpu"]
                     for k2, v2 in sec[name].items():
-                        if k2.startswith(("rank_alone_ms_w", "compute_eff_w", "whole_frame_kernel_ms")):
+                        if k2.startswith(("rank_alone_ms_w", "compute_eff_", "whole_frame_kernel_ms")):
                             out[f"{key}_{k2}"] = v2
     if not args.no_secondary:
         if env.use_dist:
