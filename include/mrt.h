@@ -129,7 +129,7 @@ enum {
     /* The default kernel exists in two shapes: a lane owns 4x4 pixels (32x32
      * pixel wave tiles) or 8x4 (64x32 tiles, 10 % fewer instructions per
      * (pixel, primitive) pair, four times fewer tiles).  The library takes 8x4
-     * for frames -- a rank's rows of one -- of at least 4 Mpixel; these two
+     * for frames -- a rank's rows of one -- of at least 3 Mpixel; these two
      * flags force one shape whatever the size (measurement and test aid; same
      * pixels out).  Both set: MRT_ERR_INVALID. */
     MRT_FLAG_TRACE_NARROW = 1u << 6,
@@ -276,7 +276,7 @@ int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uin
  * hipMalloc / hipFree (nor any other allocating call).  The array holds
  * MRT_NOALLOC_MAX_KEYS 64-bit keys (64 MiB on every GPU the library has been
  * used on, until the process ends): the rows this rank renders, padded to
- * whole block tiles (64x64 pixels, 128x64 for frames of 4 Mpixel and more),
+ * whole block tiles (64x64 pixels, 128x64 for frames of 3 Mpixel and more),
  * must fit -- a 3840x2160 frame does -- or the call fails with
  * MRT_ERR_TOO_LARGE (a MRT_FLAG_FULL_TEST context, whose kernel only merges
  * its layers in the key plane, then runs as one layer instead).  Every call on

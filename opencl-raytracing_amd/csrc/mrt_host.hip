@@ -322,12 +322,13 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         }
         return MRT_OK;
     }
-    // trace_kernel's lane block: 8x4 pixels (64x32 wave tiles) for frames of at least 4 Mpixel,
+    // trace_kernel's lane block: 8x4 pixels (64x32 wave tiles) for frames of at least 3 Mpixel,
     // 4x4 (32x32 tiles) below, where four times more tiles matter more than 10 % fewer
-    // instructions; MRT_FLAG_TRACE_NARROW / _WIDE override.  The block reject is 4x4 only.
+    // instructions (teatime alone: 1080p 0.336 ms narrow, 0.360 wide; 1440p 0.570 narrow, 0.534
+    // wide); MRT_FLAG_TRACE_NARROW / _WIDE override.  The block reject is 4x4 only.
     // (a slot of an mrt_sequence, whose frames run beside other frames: from 2 Mpixel, where the
     // smaller tile count no longer matters -- 1080p 0.313 -> 0.303 ms, 1440p 0.534 -> 0.501)
-    bool wide = (uint64_t)p.xres * p.local_rows >= ((ctx->flags & MRT_IFLAG_IN_FLIGHT) ? 2000000u : (4u << 20));
+    bool wide = (uint64_t)p.xres * p.local_rows >= ((ctx->flags & MRT_IFLAG_IN_FLIGHT) ? 2000000u : 3000000u);
     if (ctx->flags & MRT_FLAG_TRACE_NARROW) wide = false;
     if (ctx->flags & MRT_FLAG_TRACE_WIDE) wide = true;
     if (ctx->flags & (MRT_IFLAG_BLOCK_REJECT | MRT_IFLAG_SCREEN_CULL | MRT_FLAG_FULL_TEST)) wide = false;
@@ -409,10 +410,12 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     p.fuse_shade = cull ? 0u : fused;
     // trace_kernel takes the triangle list in slices, one grid layer each; the (t, id) keys merge
     // them.  A frame with few tiles needs that to fill the GPU at all (a wave alone on its SIMD
-    // issues at a fraction of the rate six reach together); a 4K frame still gains from many
-    // times more, shorter waves, because the machine spends less of the frame filling up and
-    // draining.  Target: about 128 K waves per launch.  A slice is a whole number of circle
-    // groups, at least kMinSliceTris triangles (below that the per-wave set-up dominates).
+    // issues at a fraction of the rate six reach together); a 4K frame still gains from several
+    // times more, shorter waves, because the machine spends less of the frame draining.  Target:
+    // about 64 K waves per launch, ten times what the GPU holds (measured in tile-major order,
+    // teatime: 4K best at 13-19 slices, 1080p at 26, an eighth of the 8K frame flat from 16 to 43,
+    // the 8K frame flat from 4 to 9).  A slice is a whole number of circle groups, at least
+    // kMinSliceTris triangles (below that the per-wave set-up dominates).
     p.prim_slices = 1;
     p.slice_tris = p.n_tri_padded;
     if (!full && !cull) {
@@ -424,18 +427,29 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         // this frame's wave count, and what shorter waves cost in set-up is no longer paid back:
         // about 48 K waves measured best with two frames in flight (1080p 0.343 -> 0.313 ms per
         // frame, 4K 1.095 -> 1.063, 8K 4.09 -> 4.07).
-        const uint32_t target = (ctx->flags & MRT_IFLAG_IN_FLIGHT) ? 49152u : 131072u;
+        const uint32_t target = (ctx->flags & MRT_IFLAG_IN_FLIGHT) ? 49152u : 65536u;
         uint32_t want = ctx->force_slices ? ctx->force_slices : (target + waves - 1) / waves;
+        const bool enough = want <= units;       // the list is long enough for the target
         if (want > units) want = units;
         if (want > 1) {
-            const uint32_t per = (units + want - 1) / want;
+            uint32_t per = (units + want - 1) / want;
+            // In tile-major order block b is slice b mod S of tile b / S and runs on XCD b mod 8:
+            // with S a multiple of 4 an XCD would work through the same S / 4 or S / 8 slices of
+            // every tile, whatever they cost (4K: 16 slices 1.111 ms, 13 and 15 1.097 ms).
+            // Slightly longer slices avoid that (not for a forced count, nor where the list is
+            // too short for the target anyway).
+            while (!ctx->force_slices && enough && per < units && ((units + per - 1) / per) % 4 == 0 &&
+                   (units + per - 1) / per >= mrt::kTileMajorSlices)
+                ++per;
             p.slice_tris = per * kMinSliceTris;
             p.prim_slices = (units + per - 1) / per;
         }
     } else if (full) {
         p.prim_slices = full_layers;
     }
-    const dim3 zgrid(tgrid.x, tgrid.y, p.prim_slices);
+    p.tile_major = MRT_TILE_MAJOR < 0 ? (p.prim_slices >= mrt::kTileMajorSlices ? 1u : 0u) : (uint32_t)(MRT_TILE_MAJOR != 0);
+    if (tgrid.x > 65535u || tgrid.y > 65535u) p.tile_major = 0;     // the tile would not fit grid dimensions y and z
+    const dim3 zgrid = p.tile_major ? dim3(p.prim_slices, tgrid.x, tgrid.y) : dim3(tgrid.x, tgrid.y, p.prim_slices);
     const dim3 fgrid(fgrid2.x, fgrid2.y, p.prim_slices);
     p.tile_flags = nullptr;
     p.tiles_x = pitch / tile_x;

@@ -50,6 +50,33 @@ __device__ __forceinline__ float in_vgpr(float x) {
     return x;
 }
 
+#ifdef MRT_TIMELINE
+// Diagnostic build only (tools/wave_timeline.py): every wave of trace_kernel records when it
+// started, when it had its first chunk of records in LDS and when it ended (the 100 MHz clock all
+// XCDs share), and where it ran (HW_ID and XCC_ID registers).
+constexpr uint32_t kTimelineMax = 1u << 18;
+struct TimelineEntry {
+    unsigned long long t_begin, t_staged, t_end;
+    uint32_t hw_id, xcc_id;
+    uint32_t block_x, block_y, block_z, wave;
+    unsigned long long cycles;       // shader clock ticks between begin and end
+    unsigned long long t_setup, t_sync, t_loaded;   // before the first barrier, after it, first chunk written to LDS
+    unsigned long long pad;
+};
+__device__ TimelineEntry g_timeline[kTimelineMax];
+__device__ uint32_t g_timeline_count;
+// Each mark is stored at once by lane 0 (a slot per wave of the grid, no atomics: a shared counter
+// costs the frame 0.5 ms), so that the kernel keeps no timestamps in registers.
+#define MRT_TL_SLOT (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (kBlockThreads / 64) + (threadIdx.x >> 6))
+#define MRT_TL_MARK(field)                                                                  \
+    do {                                                                                    \
+        const uint32_t tl_slot = MRT_TL_SLOT;                                               \
+        if ((threadIdx.x & 63) == 0 && tl_slot < kTimelineMax) g_timeline[tl_slot].field = wall_clock64(); \
+    } while (0)
+#else
+#define MRT_TL_MARK(field) do { } while (0)
+#endif
+
 // Image row of packed local row lr for this rank (interleaved bands).
 __device__ __forceinline__ uint32_t image_row(const RenderParams& p, uint32_t lr) {
     if (p.world == 1) return lr;              // one rank: its rows are the image's (wave-uniform branch)
@@ -267,11 +294,19 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint32_t x0 = blockIdx.x * kTrBlockX + (wave & 1) * kTrTileX + (lane & 7) * kTrLaneX;
-    const uint32_t lr0 = blockIdx.y * kTrBlockY + (wave >> 1) * kTrTileY + (lane >> 3) * kTrLaneY;
+#ifdef MRT_TIMELINE
+    MRT_TL_MARK(t_begin);
+    if (lane == 0 && MRT_TL_SLOT < kTimelineMax) g_timeline[MRT_TL_SLOT].cycles = clock64();
+#endif
+    // Launch order (see mrt_kernels.hpp): which of blockIdx's components is the slice.
+    const uint32_t blk_x = p.tile_major ? blockIdx.y : blockIdx.x;
+    const uint32_t blk_y = p.tile_major ? blockIdx.z : blockIdx.y;
+    const uint32_t blk_slice = p.tile_major ? blockIdx.x : blockIdx.z;
+    const uint32_t x0 = blk_x * kTrBlockX + (wave & 1) * kTrTileX + (lane & 7) * kTrLaneX;
+    const uint32_t lr0 = blk_y * kTrBlockY + (wave >> 1) * kTrTileY + (lane >> 3) * kTrLaneY;
     // Wave-uniform: does this wave's tile touch the image at all?
-    const uint32_t wave_x0 = blockIdx.x * kTrBlockX + (wave & 1) * kTrTileX;
-    const uint32_t wave_lr0 = blockIdx.y * kTrBlockY + (wave >> 1) * kTrTileY;
+    const uint32_t wave_x0 = blk_x * kTrBlockX + (wave & 1) * kTrTileX;
+    const uint32_t wave_lr0 = blk_y * kTrBlockY + (wave >> 1) * kTrTileY;
     const bool wave_active = (wave_x0 < p.xres) && (wave_lr0 < p.local_rows);
 
     // Pixel coordinates as floats: all the prefilters need.
@@ -295,7 +330,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     uint32_t* list_count = &s_count[wave];
     unsigned long long* tile_keys = key_plane + (size_t)wave_lr0 * pitch + wave_x0;
     // Small frames do not have enough tiles to fill the GPU, so the host may cut the triangle list
-    // into blockIdx.z slices of p.slice_tris triangles (the keys merge them: their minimum does
+    // into slices of p.slice_tris triangles, one grid layer each (the keys merge them: their minimum does
     // not depend on who found a hit).  It then initialises the key plane itself, before the
     // launch, and shades in shade_keys_kernel, after it; a single slice does both here.
     const bool single_slice = p.prim_slices <= 1;
@@ -320,6 +355,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
         if (lane == 0) *list_count = 0;
     }
     // (the first __syncthreads() of the chunk loops below orders these writes before their use)
+    MRT_TL_MARK(t_setup);
 
     unsigned long long n_exact = 0;
     bool recorded = false;           // this wave recorded a hit in the key plane
@@ -330,7 +366,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     // Record (sx, ox, sy, oy): the pixel can only hit if
     // (x*sx + ox)^2 + (y*sy + oy)^2 <= 1, an ellipse around the sphere's
     // projected bounding box grown by the error margin.
-    const uint32_t sph_end = blockIdx.z == 0 ? p.n_sph_padded : 0u;       // spheres go with the first slice
+    const uint32_t sph_end = blk_slice == 0 ? p.n_sph_padded : 0u;       // spheres go with the first slice
     for (uint32_t base = 0; base < sph_end; base += kChunkFloat4) {
         __syncthreads();
         stage_chunk(s_rec, p.sph_filter + base, tid);
@@ -390,7 +426,7 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     // ---- triangles: object ids n_sph .. n_sph+n_tri-1 ----
     // Record: 12 floats (A0,B0,C0,A1 | B1,C1,A2,B2 | C2,-,-,-); edge k passes at
     // pixel (x, y) when A_k*x + B_k*y + C_k >= 0.
-    const uint32_t tri_begin = single_slice ? 0u : blockIdx.z * p.slice_tris;
+    const uint32_t tri_begin = single_slice ? 0u : blk_slice * p.slice_tris;
     // A slice is a whole number of circle groups (the host sees to that), not of chunks.
     const uint32_t tri_end = single_slice ? p.n_tri_padded
                                           : (tri_begin + p.slice_tris < p.n_tri_padded ? tri_begin + p.slice_tris : p.n_tri_padded);
@@ -398,11 +434,20 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     for (uint32_t base = tri_begin; base < tri_end; base += kChunkTris) {
         const uint32_t staged = tri_end - base < (uint32_t)kChunkTris ? tri_end - base : (uint32_t)kChunkTris;
         __syncthreads();
+#ifdef MRT_TIMELINE
+        if (base == tri_begin) MRT_TL_MARK(t_sync);
+#endif
         stage_chunk(s_rec, p.tri_filter + (size_t)base * 3, tid, staged * 3);
 #pragma unroll
         for (int k = 0; k < kChunkTris / kBlockThreads; ++k)
             if ((uint32_t)(tid + k * kBlockThreads) < staged) s_circ[tid + k * kBlockThreads] = p.tri_circle[base + tid + k * kBlockThreads];
+#ifdef MRT_TIMELINE
+        if (base == tri_begin) MRT_TL_MARK(t_loaded);
+#endif
         __syncthreads();
+#ifdef MRT_TIMELINE
+        if (base == tri_begin) MRT_TL_MARK(t_staged);
+#endif
         if (!wave_active) continue;
 
         for (int gc = 0; gc < kChunkTris; gc += kGroupCircle) {
@@ -564,6 +609,20 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
         }
         if (p.exact_counter != nullptr && n_exact) atomicAdd(p.exact_counter, n_exact);
     }
+#ifdef MRT_TIMELINE
+    if (lane == 0) {
+        const uint32_t slot = MRT_TL_SLOT;
+        if (slot == 0) g_timeline_count = gridDim.x * gridDim.y * gridDim.z * (kBlockThreads / 64);
+        if (slot < kTimelineMax) {
+            TimelineEntry& e = g_timeline[slot];
+            e.t_end = wall_clock64();
+            e.hw_id = __builtin_amdgcn_s_getreg(4 | (31 << 11));       // HW_REG_HW_ID, all 32 bits
+            e.xcc_id = __builtin_amdgcn_s_getreg(20 | (31 << 11));     // HW_REG_XCC_ID
+            e.block_x = blk_x; e.block_y = blk_y; e.block_z = blk_slice; e.wave = (uint32_t)wave;
+            e.cycles = (unsigned long long)clock64() - e.cycles;
+        }
+    }
+#endif
 }
 
 namespace {
@@ -1504,3 +1563,20 @@ template __global__ void shade_kernel<MRT_PROJ_ORTHO>(const RenderParams, const 
 template __global__ void shade_kernel<MRT_PROJ_PERSP>(const RenderParams, const float*, const int32_t*, uint32_t);
 
 }  // namespace mrt
+
+#ifdef MRT_TIMELINE
+// Diagnostic build only: copies the wave records of everything trace_kernel ran on the current
+// device in its last launch (at most max_entries of 96 bytes each) and clears the count.
+extern "C" int mrt_debug_timeline_(void* out, uint32_t max_entries, uint32_t* n_out) {
+    uint32_t n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return MRT_ERR_HIP;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(mrt::g_timeline_count), sizeof(n)) != hipSuccess) return MRT_ERR_HIP;
+    if (n > mrt::kTimelineMax) n = mrt::kTimelineMax;
+    if (n > max_entries) n = max_entries;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(mrt::g_timeline), (size_t)n * sizeof(mrt::TimelineEntry)) != hipSuccess) return MRT_ERR_HIP;
+    const uint32_t zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mrt::g_timeline_count), &zero, sizeof(zero)) != hipSuccess) return MRT_ERR_HIP;
+    *n_out = n;
+    return MRT_OK;
+}
+#endif

@@ -57,7 +57,7 @@ def test_native_scenes_match_golden(gpu_ctx, mrt, name):
 
 @pytest.mark.parametrize("name", ALL_SCENES)
 def test_native_scenes_wide_lane_blocks_match_golden(mrt, name):
-    """The 8x4-pixels-per-lane shape of the default kernel (what frames of 4 Mpixel and more get),
+    """The 8x4-pixels-per-lane shape of the default kernel (what frames of 3 Mpixel and more get),
     forced onto the 400x400 scenes: 64x32 wave tiles, 128x64 block tiles, 64-bit pixel masks."""
     g = np.load(GOLDEN / f"{name}.npz")
     ctx = mrt.Context(device=0, flags=mrt.FLAG_TRACE_WIDE)

@@ -26,6 +26,9 @@ import mkscene  # noqa: E402
 
 
 
+WARM_SECONDS = 0.06
+
+
 def rank_alone(mrt, scene, world, rank, reps, flags=0, band=None):
     """Median device time (HIP events inside the library: trace + shade), wall time per frame of
     `reps` frames enqueued back to back on one context, and wall time per frame with two frames in
@@ -37,9 +40,13 @@ def rank_alone(mrt, scene, world, rank, reps, flags=0, band=None):
     ctx = mrt.Context(device=0, flags=flags)
     try:
         ctx.set_scene(scene)
-        for _ in range(2):
-            ctx.render_bands_device(BAND, rank, world, buf.data_ptr(), buf.numel() * 4)
-        torch.cuda.synchronize()
+        # the clock climbs for the first 25 ms of work or so: a short launch timed cold looks
+        # slower than it is, and a rank's share more so than the whole frame
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < WARM_SECONDS:
+            for _ in range(4):
+                ctx.render_bands_device(BAND, rank, world, buf.data_ptr(), buf.numel() * 4)
+            torch.cuda.synchronize()
         ev = []
         for _ in range(reps):
             s = ctx.render_bands_device(BAND, rank, world, buf.data_ptr(), buf.numel() * 4, timed=True)
@@ -56,9 +63,11 @@ def rank_alone(mrt, scene, world, rank, reps, flags=0, band=None):
     try:
         seq.set_scene(scene)
         bufs = [buf, torch.empty_like(buf)]
-        for k in range(4):
-            seq.submit(BAND, rank, world, bufs[k % 2].data_ptr(), buf.numel() * 4)
-        seq.wait()
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < WARM_SECONDS:
+            for k in range(4):
+                seq.submit(BAND, rank, world, bufs[k % 2].data_ptr(), buf.numel() * 4)
+            seq.wait()
         n = max(reps, 4) * 2
         t0 = time.perf_counter()
         for k in range(n):
