@@ -296,9 +296,12 @@ def secondary_workloads(env, mkscene):
         if env.world != 1:
             return
         import time_rank_alone
-        b = time_rank_alone.strong_scaling_bound(mrt, scene, reps=reps)
+        # bands as the multi-GPU paths cut them (mrt_balanced_band_rows: 64 rows, or 32 where that leaves
+        # the busiest rank fewer -- 4320 rows over 8 ranks: 544 instead of 576 against a mean of 540)
+        b = time_rank_alone.strong_scaling_bound(mrt, scene, reps=reps, band="balanced")
         res[name]["whole_frame_kernel_ms"] = b["full_frame"]["kernel_ms"]
         for w in (2, 4, 8):
+            res[name][f"rank_alone_band_rows_w{w}"] = b[f"w{w}"]["band_rows"]
             res[name][f"rank_alone_ms_w{w}"] = b[f"w{w}"]["rank_alone_ms"]
             res[name][f"compute_eff_w{w}"] = b[f"w{w}"]["compute_eff"]
             res[name][f"compute_eff_back_to_back_w{w}"] = b[f"w{w}"]["compute_eff_back_to_back"]
@@ -708,7 +711,7 @@ def main():
                         out[f"{key}_one_gpu_ms_per_frame"] = sec[name]["one_gpu_ms_per_frame"]
                         out[f"{key}_speedup_vs_one_gpu"] = sec[name]["speedup_vs_one_gpu"]
                     for k2, v2 in sec[name].items():
-                        if k2.startswith(("rank_alone_ms_w", "compute_eff_", "whole_frame_kernel_ms")):
+                        if k2.startswith(("rank_alone_ms_w", "rank_alone_band_rows_w", "compute_eff_", "whole_frame_kernel_ms")):
                             out[f"{key}_{k2}"] = v2
     if not args.no_secondary:
         if env.use_dist:
