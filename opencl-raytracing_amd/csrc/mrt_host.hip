@@ -24,7 +24,7 @@
 #include <vector>
 
 namespace mrt {
-template <int PROJ, bool BLOCK_REJECT, int LX, int LY>
+template <int PROJ, bool BLOCK_REJECT, int LX, int LY, bool SLICED>
 __global__ void trace_kernel(const RenderParams p, unsigned long long* key_plane, float* t_out, int32_t* id_out,
                              uint32_t pitch);
 template <int PROJ>
@@ -477,6 +477,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     } else if (d_key != nullptr && planes.own) {
         ctx->keys_clean = false;               // a single-slice frame initialises and leaves its own keys
     }
+    const bool sliced = p.prim_slices > 1;       // trace_kernel without its epilogue: shade_keys_kernel finishes the frame
     uint32_t kernel;
     if (full && persp) {
         kernel = MRT_KERNEL_FULL;
@@ -494,22 +495,28 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
         hipLaunchKernelGGL((mrt::cull_trace_kernel<MRT_PROJ_ORTHO>), cgrid, tb, 0, stream, p, d_t, d_id, pitch);
     } else if (persp && block) {
         kernel = MRT_KERNEL_TRACE_BLOCK;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        if (sliced) hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true, 4, 4, true>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        else hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, true, 4, 4, false>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else if (persp && wide) {
         kernel = MRT_KERNEL_TRACE_WIDE;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, mrt::TraceWide::lane_x, mrt::TraceWide::lane_y>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        if (sliced) hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, mrt::TraceWide::lane_x, mrt::TraceWide::lane_y, true>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        else hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, mrt::TraceWide::lane_x, mrt::TraceWide::lane_y, false>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else if (persp) {
         kernel = MRT_KERNEL_TRACE;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        if (sliced) hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, 4, 4, true>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        else hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_PERSP, false, 4, 4, false>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else if (block) {
         kernel = MRT_KERNEL_TRACE_BLOCK;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        if (sliced) hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true, 4, 4, true>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        else hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, true, 4, 4, false>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else if (wide) {
         kernel = MRT_KERNEL_TRACE_WIDE;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, mrt::TraceWide::lane_x, mrt::TraceWide::lane_y>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        if (sliced) hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, mrt::TraceWide::lane_x, mrt::TraceWide::lane_y, true>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        else hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, mrt::TraceWide::lane_x, mrt::TraceWide::lane_y, false>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     } else {
         kernel = MRT_KERNEL_TRACE;
-        hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, 4, 4>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        if (sliced) hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, 4, 4, true>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
+        else hipLaunchKernelGGL((mrt::trace_kernel<MRT_PROJ_ORTHO, false, 4, 4, false>), zgrid, tb, 0, stream, p, d_key, d_t, d_id, pitch);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], stream));

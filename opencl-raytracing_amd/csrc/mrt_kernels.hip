@@ -266,7 +266,7 @@ __device__ __forceinline__ uint32_t list_pixels(MASK mask, uint32_t bx, uint32_t
 
 }  // namespace
 
-template <int PROJ, bool BLOCK_REJECT, int LX, int LY>
+template <int PROJ, bool BLOCK_REJECT, int LX, int LY, bool SLICED>
 __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace_kernel(const RenderParams p,
                                                              unsigned long long* __restrict__ key_plane,
                                                              float* __restrict__ t_out,
@@ -333,7 +333,9 @@ __global__ __launch_bounds__(kBlockThreads, MRT_TRACE_WAVES_PER_SIMD) void trace
     // into slices of p.slice_tris triangles, one grid layer each (the keys merge them: their minimum does
     // not depend on who found a hit).  It then initialises the key plane itself, before the
     // launch, and shades in shade_keys_kernel, after it; a single slice does both here.
-    const bool single_slice = p.prim_slices <= 1;
+    // SLICED is a template parameter because the epilogue (shading) is what costs registers: built
+    // without it the kernel spills nothing and uses no scratch memory at all.
+    constexpr bool single_slice = !SLICED;
     if (wave_active) {
         if (single_slice) {
 #pragma unroll
@@ -1542,12 +1544,18 @@ __global__ __launch_bounds__(256) void shade_kernel(const RenderParams p,
     p.out[(size_t)lr * p.xres + x] = shade_pixel<PROJ>(p, x, image_row(p, lr), t_in[src], id_in[src]);
 }
 
-template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_PERSP, false, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, TraceWide::lane_x, TraceWide::lane_y>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_PERSP, false, TraceWide::lane_x, TraceWide::lane_y>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_ORTHO, true, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
-template __global__ void trace_kernel<MRT_PROJ_PERSP, true, 4, 4>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, 4, 4, false>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, 4, 4, true>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, false, 4, 4, false>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, false, 4, 4, true>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, TraceWide::lane_x, TraceWide::lane_y, false>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, false, TraceWide::lane_x, TraceWide::lane_y, true>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, false, TraceWide::lane_x, TraceWide::lane_y, false>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, false, TraceWide::lane_x, TraceWide::lane_y, true>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, true, 4, 4, false>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_ORTHO, true, 4, 4, true>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, true, 4, 4, false>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
+template __global__ void trace_kernel<MRT_PROJ_PERSP, true, 4, 4, true>(const RenderParams, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void full_trace_kernel<MRT_PROJ_ORTHO>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void full_trace_kernel<MRT_PROJ_PERSP>(const RenderParams, const float4*, const uint32_t*, const uint32_t*, unsigned long long*, float*, int32_t*, uint32_t);
 template __global__ void prep_full_records<MRT_PROJ_ORTHO>(const RenderParams, float4*, uint32_t*, uint32_t*);

@@ -1,17 +1,19 @@
 #!/bin/bash
-# GPU box: trace_kernel's launch order, tile-major (the product) against slice-major
-# (variants/slice_major, built with -DMRT_TILE_MAJOR=0), three interleaved rounds.
+# GPU box: the library as built (main) against variants/<name>/libmrt_hip.so on the frames the
+# strong-scaling bound is taken on (tools/time_rank_alone.py: the 4K and 8K teatime frames whole and
+# as ranks 0 and w - 1 of 2, 4 and 8), three interleaved rounds.  usage: bash tools/ab_variant.sh <name>
+V=${1:?variant name}
 mkdir -p gpurun_out/ab
 for round in 1 2 3; do
-  for v in main slice_major; do
+  for v in main $V; do
     if [ $v = main ]; then unset MRT_HIP_LIB; else export MRT_HIP_LIB=$PWD/variants/$v/libmrt_hip.so; fi
     timeout -k 10 200 python -u tools/time_rank_alone.py teatime4k --band balanced --reps 20 > gpurun_out/ab/$v.4k.$round.log 2>&1 || exit 1
     timeout -k 10 200 python -u tools/time_rank_alone.py teatime8k --band balanced --reps 20 > gpurun_out/ab/$v.8k.$round.log 2>&1 || exit 1
   done
 done
-python3 - <<'PY'
-import glob, re, ast
-for v in ("main", "slice_major"):
+python3 - "$V" <<'PY'
+import glob, re, ast, sys
+for v in ("main", sys.argv[1]):
     for f in ("4k", "8k"):
         rows = []
         for path in sorted(glob.glob(f"gpurun_out/ab/{v}.{f}.?.log")):
