@@ -262,7 +262,7 @@ def test_committed_profile_feeds_the_bench_line():
     assert bench.profiled_traffic(full) > 0
     default, _ = bench.profiled_counters("mrt::trace_kernel")
     assert 1.5 < default["SQ_INSTS_VALU"] * 64 / pairs < 3.0
-    assert default["SQ_WAVES"] == 130560                                # a context's 4K frame in 32 slices
+    assert default["SQ_WAVES"] == 61200                                 # a context's 4K frame: 30 x 34 blocks of 128 x 64 pixels, four waves each, 15 slices
     assert bench.algorithmic_flops(type("S", (), {"n_tris": 4032, "n_spheres": 2}), 3840 * 2160) == 1505267712000.0
 
 
