@@ -289,10 +289,14 @@ int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uin
  * enqueues anything, and the capture stays valid.  Replaying a recorded frame
  * ended in a GPU memory fault each of the three times it was tried (with the
  * default and with the MRT_FLAG_FULL_TEST kernels, through torch.cuda.graph and
- * through hipStreamBeginCapture directly); what the recordings had in common --
- * a memset node on the fixed array, which is a __device__ symbol and not a
- * hipMalloc'ed buffer, and kernels that take a 300-byte structure by value --
- * was not taken apart further.
+ * through hipStreamBeginCapture directly).  What such a recording holds that
+ * ordinary captured work may not -- a memset node on the fixed array, which is
+ * a __device__ symbol and not a hipMalloc'ed buffer, and kernels that take a
+ * 328-byte structure by value -- replays correctly when recorded on its own
+ * (tools/graph_probe.hip), and the nodes of a recorded frame hold the grid,
+ * the block and, byte for byte, the arguments of the eager call
+ * (tools/graph_frame_probe.cpp on a -DMRT_ALLOW_CAPTURE build): the cause is
+ * not in what the library records, and a replay was not risked again.
  * No counterpart in the reference, which allocates in every stage call
  * (CLHelpers.hpp:93-104). */
 #define MRT_NOALLOC_MAX_KEYS (8u * 1024u * 1024u)

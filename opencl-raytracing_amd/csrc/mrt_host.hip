@@ -303,9 +303,20 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     // A stream that is recording a HIP graph is refused: replaying a recorded frame ended in a GPU
     // memory fault every time it was tried (default and full-test kernels alike), so the call
     // fails cleanly here, before anything is enqueued, and the capture stays valid.
-    if (stream_is_capturing(stream))
+    const bool capturing = stream_is_capturing(stream);
+#ifndef MRT_ALLOW_CAPTURE
+    if (capturing)
         return fail(ctx, MRT_ERR_INVALID,
                     "the stream is capturing a HIP graph: frames cannot be recorded into a graph (not supported)");
+#else
+    // Diagnostic build only (tools/graph_frame_probe.cpp): the frame that allocates nothing may be
+    // recorded, provided nothing of this context is pending on another stream; no event of the
+    // context is recorded into the graph or waited on by it.
+    if (capturing && (planes.own || timed))
+        return fail(ctx, MRT_ERR_INVALID, "only mrt_render_bands_device_noalloc can be captured");
+    if (capturing && ((ctx->frame_pending && stream != ctx->last_stream) || (ctx->records_pending && stream != ctx->stream)))
+        return fail(ctx, MRT_ERR_INVALID, "work of this context is pending on another stream: mrt_synchronize first");
+#endif
     RenderParams p = ctx->params;
     p.band_rows = band_rows;
     p.rank = rank;
@@ -543,9 +554,11 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     ctx->last_pitch = pitch;
     // Every frame, whatever planes it worked in, reads the per-view records: mrt_set_camera orders
     // its rebuild behind this event.
-    HIP_TRY(ctx, hipEventRecord(ctx->frame_done, stream));
-    ctx->last_stream = stream;
-    ctx->frame_pending = true;
+    if (!capturing) {
+        HIP_TRY(ctx, hipEventRecord(ctx->frame_done, stream));
+        ctx->last_stream = stream;
+        ctx->frame_pending = true;
+    }
     return MRT_OK;
 }
 
