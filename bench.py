@@ -604,8 +604,8 @@ def main():
     job.close()
 
     # The same frame (this rank's rows of it) with MRT_FLAG_FULL_TEST: no rejection in screen space,
-    # a general-ray 3x3 solve for every (ray, triangle) pair -- the kernel whose executed arithmetic
-    # is the priced arithmetic, hence the one the roofline is about.
+    # the determinants of the 3x3 solve for every (ray, triangle) pair (37 of the 45 priced FLOPs: the
+    # frame's rays share origin or direction) -- the kernel the roofline is about.
     fjob = Job(env, sc, flags=mrt.FLAG_FULL_TEST)
     full_reps = max(3, min(args.steps, 10))
     full_elapsed = fjob.timed(full_reps, 1)

@@ -458,7 +458,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     } else if (full) {
         p.prim_slices = full_layers;
     }
-    p.tile_major = MRT_TILE_MAJOR < 0 ? (p.prim_slices >= mrt::kTileMajorSlices ? 1u : 0u) : (uint32_t)(MRT_TILE_MAJOR != 0);
+    p.tile_major = (full || cull) ? 0u : (MRT_TILE_MAJOR < 0 ? (p.prim_slices >= mrt::kTileMajorSlices ? 1u : 0u) : (uint32_t)(MRT_TILE_MAJOR != 0));
     if (tgrid.x > 65535u || tgrid.y > 65535u) p.tile_major = 0;     // the tile would not fit grid dimensions y and z
     const dim3 zgrid = p.tile_major ? dim3(p.prim_slices, tgrid.x, tgrid.y) : dim3(tgrid.x, tgrid.y, p.prim_slices);
     const dim3 fgrid(fgrid2.x, fgrid2.y, p.prim_slices);

@@ -22,8 +22,12 @@
 //                      survive run the reference arithmetic (mrt_device.hpp),
 //                      in object order, so the accepted hits, their t and the
 //                      winner are those of the reference loop.
-//   full_trace_kernel  MRT_FLAG_FULL_TEST: a general-ray 3x3 solve (fused) for
-//                      every pair, the reference arithmetic for the survivors.
+//   full_trace_kernel  MRT_FLAG_FULL_TEST: the determinants of the 3x3 solve
+//                      (fused) for every pair, no rejection in screen space,
+//                      the reference arithmetic for the survivors.  The rays
+//                      of a frame share origin or direction and the per-view
+//                      records fold that half in: not a general-ray kernel
+//                      (that one is general_intersect_kernel, mrt_stages.hip).
 //   cull_trace_kernel  not a brute-force kernel (mrt_accel_*): lanes first test
 //                      64 primitives each against the whole wave tile.
 //   grid_trace_kernel  not a brute-force kernel either (mrt_accel_*): walks the
@@ -1068,8 +1072,11 @@ __global__ __launch_bounds__(kBlockThreads) void grid_trace_kernel(const RenderP
 }
 
 // ---------------------------------------------------------------------------
-// MRT_FLAG_FULL_TEST: a general-ray 3x3 solve for EVERY (pixel, primitive)
-// pair -- no screen-space rejection of any kind.
+// MRT_FLAG_FULL_TEST: the determinants of the 3x3 solve for EVERY (pixel,
+// primitive) pair -- no screen-space rejection of any kind.  (Not a general-ray
+// kernel: prep_full_records folds the origin all rays of a pinhole frame
+// share, or the direction all rays of an orthographic one share, into the
+// per-view records.)
 //
 // tri_intersect (kernel.cl:197-235) solves by Cramer's rule: four 3x3
 // determinants det, Nb, Ng, Nt, then beta = Nb/det, gamma = Ng/det, t = Nt/det
