@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 6
+#define MRT_ABI_VERSION 7
 
 typedef enum mrt_status {
     MRT_OK = 0,
@@ -133,7 +133,18 @@ enum {
      * flags force one shape whatever the size (measurement and test aid; same
      * pixels out).  Both set: MRT_ERR_INVALID. */
     MRT_FLAG_TRACE_NARROW = 1u << 6,
-    MRT_FLAG_TRACE_WIDE = 1u << 7
+    MRT_FLAG_TRACE_WIDE = 1u << 7,
+    /* mrt_create normally brings the fixed array of
+     * mrt_render_bands_device_noalloc onto the GPU (64 MiB: 23 ms of the first
+     * context's start-up, and 5 ms of the first frame's), so that no call of
+     * that entry point ever sets anything up.  A caller that will not use it --
+     * the mrraytracer CLI -- sets this flag and mrt_create leaves the array
+     * alone: a process that never calls the entry point never pays for it, and
+     * one that does after all pays on its first such call on that GPU (which
+     * then loads the array; later calls allocate nothing, as documented).
+     * mrt_multi_*, mrt_sequence_* and mrt_accel_* have no such entry point
+     * and always leave the array alone.  (ABI version 7.) */
+    MRT_FLAG_DEFER_NOALLOC_SETUP = 1u << 8
     /* (bit 30 is reserved: the library marks the slots of an mrt_sequence with it) */
 };
 

@@ -22,11 +22,12 @@ FLAG_NO_CIRCLE = 1 << 3
 FLAG_FULL_TEST = 1 << 5
 FLAG_TRACE_NARROW = 1 << 6          # trace_kernel with 4x4 pixels per lane whatever the frame size
 FLAG_TRACE_WIDE = 1 << 7            # ... with 8x4
+FLAG_DEFER_NOALLOC_SETUP = 1 << 8   # mrt_create leaves the fixed array of the no-alloc entry point off the GPU
 RESERVED_FLAG_BITS = (1 << 2) | (1 << 4) | (1 << 30)          # mrt_create refuses them
 KERNEL_TRACE, KERNEL_TRACE_BLOCK, KERNEL_CULL, KERNEL_FULL, KERNEL_GRID, KERNEL_TRACE_WIDE = 0, 1, 2, 3, 4, 5    # mrt_stats.kernel
 ACCEL_GRID, ACCEL_TILE_CULL, ACCEL_BLOCK_REJECT = 0, 1, 2                                 # mrt_accel_config.method
 ACCEL_METHODS = {"grid": ACCEL_GRID, "cull": ACCEL_TILE_CULL, "block": ACCEL_BLOCK_REJECT}
-ABI_VERSION = 6
+ABI_VERSION = 7
 PROJ_ORTHO, PROJ_PERSP = 0, 1
 SHADER_FLAT, SHADER_PHONG = 0, 1
 

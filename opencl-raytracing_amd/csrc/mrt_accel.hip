@@ -590,6 +590,7 @@ int mrt_accel_create(const mrt_accel_config* cfg, mrt_accel** out) {
     inner.device = cfg ? cfg->device : -1;
     inner.flags = flags | (method == MRT_ACCEL_TILE_CULL ? (uint32_t)MRT_IFLAG_SCREEN_CULL
                            : method == MRT_ACCEL_BLOCK_REJECT ? (uint32_t)MRT_IFLAG_BLOCK_REJECT : 0u);
+    inner.flags |= MRT_FLAG_DEFER_NOALLOC_SETUP;         // no entry point of mrt_accel uses the fixed array
     mrt_ctx* base = nullptr;
     const int rc = mrt_create_internal_(&inner, &base);
     if (rc != MRT_OK) return afail(nullptr, rc, mrt_last_error(nullptr));

@@ -687,8 +687,13 @@ int mrt_create_internal_(const mrt_config* cfg, mrt_ctx** out) {
     if ((e = hipMalloc((void**)&ctx->d_counter, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     const double malloc_ms = ms_since(t2);
     const auto t3 = clk::now();
-    if ((e = scratch_address(dev, &ctx->scratch_keys)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
-    const double code_object_ms = ms_since(t3);        // the library's code object is loaded onto the GPU, its 64 MiB array with it
+    // The fixed array of mrt_render_bands_device_noalloc is brought onto the GPU here, once per
+    // device, unless the caller has said that it will not use that entry point (or cannot: the
+    // contexts inside mrt_multi / mrt_sequence / mrt_accel handles); the entry point's first call
+    // on the device does it then.
+    if (!(ctx->flags & MRT_FLAG_DEFER_NOALLOC_SETUP))
+        if ((e = scratch_address(dev, &ctx->scratch_keys)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
+    const double code_object_ms = ms_since(t3);        // the code object that holds the 64 MiB array is loaded onto the GPU
     if (stats)
         std::fprintf(stderr, "{\"mrt_create\": {\"runtime_start_ms\": %.3f, \"first_stream_ms\": %.3f, \"first_malloc_ms\": %.3f, "
                              "\"code_object_load_ms\": %.3f, \"total_ms\": %.3f}}\n",
@@ -1020,6 +1025,9 @@ int mrt_render_bands_device_noalloc(mrt_ctx* ctx, uint32_t band_rows, uint32_t r
     // The key plane is this GPU's copy of the fixed array, shared by every such call on the GPU and
     // holding whatever the last one left: launch_frame clears the part this frame uses (a memset
     // for a sliced frame, the kernel's prologue otherwise) and never allocates in this mode.
+    // (a context created with MRT_FLAG_DEFER_NOALLOC_SETUP: this device's copy of the array is
+    // taken now, on the entry point's first call on the device)
+    if (!ctx->scratch_keys) HIP_TRY(ctx, scratch_address(ctx->device, &ctx->scratch_keys));
     FramePlanes planes;
     planes.own = false;
     planes.key = ctx->scratch_keys;

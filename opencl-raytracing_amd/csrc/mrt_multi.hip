@@ -224,7 +224,7 @@ int mrt_multi_create(const mrt_multi_config* cfg, mrt_multi** out) {
     for (uint32_t r = 0; r < world; ++r) {
         Rank& k = m->ranks[r];
         k.device = devs[r];
-        mrt_config c = {devs[r], m->flags};
+        mrt_config c = {devs[r], m->flags | MRT_FLAG_DEFER_NOALLOC_SETUP};    // no entry point of mrt_multi uses the fixed array
         const int rc = mrt_create(&c, &k.ctx);
         if (rc != MRT_OK) return bail(rc, std::string("rank ") + std::to_string(r) + ": " + mrt_last_error(nullptr));
         if ((e = hipSetDevice(k.device)) != hipSuccess) return bail(MRT_ERR_HIP, hipGetErrorString(e));

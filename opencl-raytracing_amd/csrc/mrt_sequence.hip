@@ -113,6 +113,7 @@ int mrt_sequence_create(const mrt_sequence_config* cfg, mrt_sequence** out) {
         mrt_config c = {cfg ? cfg->device : -1, cfg ? cfg->flags : 0u};
         if (k > 0) c.device = q->device;                 // "-1" must mean the same GPU for every slot
         if (n > 1) c.flags |= MRT_IFLAG_IN_FLIGHT;       // slices sized for a GPU that other frames keep full
+        c.flags |= MRT_FLAG_DEFER_NOALLOC_SETUP;         // no entry point of mrt_sequence uses the fixed array
         const int rc = mrt_create_internal_(&c, &q->slots[k].ctx);
         if (rc != MRT_OK) {
             const std::string msg = mrt_last_error(nullptr);

@@ -161,7 +161,8 @@ int main(int argc, char** argv) {
         mrt_accel_config ac = {-1, static_cast<uint32_t>(accel_method), 0u};
         rc = mrt_accel_create(&ac, &actx);
     } else {
-        mrt_config cfg = {-1, flags};
+        // (the CLI never renders through the entry point that allocates nothing: its 64 MiB array stays off the GPU)
+        mrt_config cfg = {-1, flags | MRT_FLAG_DEFER_NOALLOC_SETUP};
         rc = mrt_create(&cfg, &ctx);
     }
     const double ctx_create_ms = ms_since(t_create);   // HIP start-up, code-object load, streams

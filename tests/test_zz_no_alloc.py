@@ -103,6 +103,42 @@ def test_noalloc_other_kernels_and_limits(mrt):
         ctx.close()
 
 
+_DEFERRED_SNIPPET = r"""
+import sys
+sys.path[:0] = [{root!r}, {root!r} + "/tools"]
+import numpy as np
+import torch
+import mrt_pkg, mkscene
+mrt = mrt_pkg.load()
+ctx = mrt.Context(device=0, flags=mrt.FLAG_DEFER_NOALLOC_SETUP)      # the only context of this process
+ok = True
+for xres, yres, band, rank, world in ((1280, 720, 720, 0, 1), (640, 360, 64, 1, 2)):
+    sc = mrt.LoadedScene(text=mkscene.teatime(xres, yres)).copy()
+    ctx.set_scene(sc)
+    n = mrt.band_rows(yres, band, rank, world) * xres * 4
+    ref = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    out = torch.full((n,), 0x5A, dtype=torch.uint8, device="cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.render_bands_device(band, rank, world, ref.data_ptr(), n, stream=s)
+    ctx.render_bands_device_noalloc(band, rank, world, out.data_ptr(), n, stream=s)
+    torch.cuda.synchronize()
+    ok = ok and bool(torch.equal(ref, out)) and len(np.unique(ref.cpu().numpy().reshape(-1, 4), axis=0)) > 100
+ctx.close()
+print("deferred set-up:", "same bytes" if ok else "DIFFERENT")
+"""
+
+
+def test_noalloc_on_a_context_that_deferred_the_set_up():
+    """MRT_FLAG_DEFER_NOALLOC_SETUP: mrt_create leaves the fixed array alone (what the CLI asks for).
+    In a process of its own, whose only context has the flag, the entry point's first call takes
+    the array and writes the bytes of the allocating entry point; a second, smaller call too."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", _DEFERRED_SNIPPET.format(root=str(ROOT))], capture_output=True, text=True,
+                       timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "deferred set-up: same bytes" in r.stdout, r.stdout[-500:]
+
+
 def test_noalloc_leaves_free_memory_alone(mrt):
     """Free device memory as the driver reports it does not shrink across calls (after one call
     of each entry point has loaded whatever the runtime loads lazily)."""
