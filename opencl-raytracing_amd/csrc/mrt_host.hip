@@ -234,7 +234,7 @@ int check_scene(mrt_ctx* ctx, const mrt_scene* s) {
 
 // Working planes of a frame, grown on demand: the 64-bit key plane of trace_kernel, and the
 // (t, id) planes that mrt_render_debug returns and cull_trace_kernel hands to shade_kernel.
-int ensure_keys(mrt_ctx* ctx, size_t elems) {
+int ensure_keys(mrt_ctx* ctx, size_t elems, hipStream_t stream) {
     if (elems <= ctx->key_elems) return MRT_OK;
     if (ctx->d_key) { (void)hipFree(ctx->d_key); ctx->d_key = nullptr; }
     ctx->key_elems = 0;
@@ -247,9 +247,11 @@ int ensure_keys(mrt_ctx* ctx, size_t elems) {
         if (ctx->d_tile_flags) { (void)hipFree(ctx->d_tile_flags); ctx->d_tile_flags = nullptr; }
         ctx->tile_flag_elems = 0;
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tile_flags, tiles * sizeof(uint32_t)));
-        // no frame's tag; done before any stream uses the new buffer (growth is rare)
-        HIP_TRY(ctx, hipMemset(ctx->d_tile_flags, 0, tiles * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipDeviceSynchronize());
+        // No frame's tag.  On the stream of the frame that is about to use the new buffer: nothing
+        // else knows it yet, and a later frame on another stream is ordered behind this one.  (Not
+        // on the null stream: the first use of that one makes the runtime create its hardware
+        // queue, 3 ms of a process's first frame.)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_tile_flags, 0, tiles * sizeof(uint32_t), stream));
         ctx->tile_flag_elems = tiles;
     }
     return MRT_OK;
@@ -386,7 +388,7 @@ int launch_frame(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world
     int32_t* d_id = nullptr;
     if ((!full && !cull) || full_layers > 1) {
         if (planes.own) {
-            const int rc = ensure_keys(ctx, plane_elems);
+            const int rc = ensure_keys(ctx, plane_elems, stream);
             if (rc != MRT_OK) return rc;
             d_key = ctx->d_key;
         } else {

@@ -17,6 +17,8 @@
 //   MRT_GPU_LIST=a,b,. the HIP ordinals of the ranks instead of 0 .. n-1; an ordinal may repeat
 //   MRT_GATHER=rccl|peer|host   how the bands reach the host image (default: RCCL if it can)
 //   MRT_REPEAT=<k>     render the frame k more times and report the fastest (with MRT_STATS)
+//   HSA_ENABLE_SDMA=1  (a setting of the ROCm runtime) copies through the DMA engines; the driver
+//                      sets it to 0 for itself unless the caller has set it
 #include "mrt.h"
 
 #include <cstdio>
@@ -89,6 +91,13 @@ int main(int argc, char** argv) {
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     const auto t_start = clk::now();
 
+    // A process that renders one frame gains nothing from the DMA engines and pays for bringing
+    // them up: the first copy in either direction costs 5-6 ms when it goes through one (teatime
+    // at 400x400: 42 -> 32 ms in all, at 3840x2160 60 -> 47; the 1 GiB frame of the 16384^2 soup
+    // leaves the GPU as fast through copy kernels).  Unless the caller has said otherwise, copies
+    // run as kernels.  (A setting of the runtime for this process only; the library itself
+    // leaves it to its host application.)
+    setenv("HSA_ENABLE_SDMA", "0", 0);
     // What the environment asks for (a mistake in it is reported where the render would start).
     std::string env_error;
     uint32_t flags = MRT_FLAG_NONE;
