@@ -91,13 +91,6 @@ int main(int argc, char** argv) {
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     const auto t_start = clk::now();
 
-    // A process that renders one frame gains nothing from the DMA engines and pays for bringing
-    // them up: the first copy in either direction costs 5-6 ms when it goes through one (teatime
-    // at 400x400: 42 -> 32 ms in all, at 3840x2160 60 -> 47; the 1 GiB frame of the 16384^2 soup
-    // leaves the GPU as fast through copy kernels).  Unless the caller has said otherwise, copies
-    // run as kernels.  (A setting of the runtime for this process only; the library itself
-    // leaves it to its host application.)
-    setenv("HSA_ENABLE_SDMA", "0", 0);
     // What the environment asks for (a mistake in it is reported where the render would start).
     std::string env_error;
     uint32_t flags = MRT_FLAG_NONE;
@@ -136,6 +129,15 @@ int main(int argc, char** argv) {
         if (env_error.empty() && multi) env_error = "error: MRT_ACCEL renders on one GPU; unset MRT_GPUS / MRT_GPU_LIST";
     }
     const bool accel = accel_method >= 0 && env_error.empty();
+
+    // A process that renders one frame gains nothing from the DMA engines and pays for bringing
+    // them up: the first copy in either direction costs 5-6 ms when it goes through one (teatime
+    // at 400x400: 42 -> 32 ms in all, at 3840x2160 60 -> 47; the 1 GiB frame of the 16384^2 soup
+    // leaves the GPU as fast through copy kernels).  Unless the caller has said otherwise, copies
+    // run as kernels.  (A setting of the runtime for this process only; the library itself
+    // leaves it to its host application.)
+    // Only with one GPU: copies between GPUs are left as the runtime does them.
+    if (!multi) setenv("HSA_ENABLE_SDMA", "0", 0);
 
     // The GPU side of the start-up (HIP runtime, a hardware queue, the context: 23 ms) runs on a
     // thread of its own while this one reads the scene file and prints the summary.
