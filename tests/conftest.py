@@ -18,6 +18,15 @@ SMALL_SCENES = [
 ALL_SCENES = SMALL_SCENES + ["teatime"]
 
 
+def free_port():
+    """A TCP port nothing listens on right now, for a torch.distributed rendezvous on 127.0.0.1 (a
+    fixed number could be taken by another job on the machine)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -8,7 +8,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,7 @@ def test_bench_line_has_the_contract_keys():
 def test_bench_two_ranks_rehearsal():
     env = dict(os.environ, MRT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29561", str(ROOT / "bench.py"), "--gpus", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(ROOT / "bench.py"), "--gpus", "2",
                         "--steps", "3", "--warmup", "1", "--no-secondary"], capture_output=True, text=True,
                        timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-2000:]

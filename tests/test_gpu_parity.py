@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import SCENES, GOLDEN, ALL_SCENES, ROOT
+from conftest import SCENES, GOLDEN, ALL_SCENES, ROOT, free_port
 from parity import check
 
 sys.path.insert(0, str(ROOT / "tools"))
@@ -994,7 +994,7 @@ def test_dist_cli_two_ranks_on_one_gpu(tmp_path):
     out = tmp_path / "dist.png"
     env = dict(os.environ, MRT_DIST_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script),
                         str(SCENES / f"{name}.json"), str(out)], capture_output=True, text=True, env=env,
                        timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]

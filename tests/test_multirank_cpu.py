@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, SCENES
+from conftest import ROOT, SCENES, free_port
 import scene_py
 
 
@@ -17,7 +17,7 @@ def test_gloo_band_gather_roundtrip(oracle, tmp_path, world, band, yres):
     xres = 80
     out = tmp_path / "img.npy"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    port = 29500 + (os.getpid() % 2000)
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            str(ROOT / "tests" / "multirank_worker.py"), "scene_2spheres_persp_phong", str(xres), str(yres),
