@@ -3,6 +3,7 @@ loader (schema, validation order and messages of rayson.hpp:380-638), the band
 partition helpers, the PNG writer and the CLI contract (mrraytracer.cpp:23-148)."""
 import ctypes
 import json
+import os
 import subprocess
 import sys
 from pathlib import Path
@@ -220,6 +221,21 @@ def test_cli_usage_and_errors(tmp_path):
     assert r.returncode == 1
     assert r.stderr == f'error loading scene "{bad}": no materials list\n'
     assert r.stdout == ""
+
+
+def test_cli_reports_a_bad_environment_where_the_render_would_start(tmp_path):
+    """A mistake in the optional environment does not change what the two-argument contract prints
+    first: the scene summary and "raytracing..." come out as always, then the error, exit status 1,
+    and no PNG is written.  (Needs no GPU: nothing is created for a request that cannot be served.)"""
+    out = tmp_path / "o.png"
+    for env_extra, message in (({"MRT_ACCEL": "bogus"}, "error: MRT_ACCEL must be grid, cull or block"),
+                               ({"MRT_ACCEL": "grid", "MRT_GPUS": "2"}, "error: MRT_ACCEL renders on one GPU")):
+        r = subprocess.run([str(CLI), str(SCENES / "scene_gtri_ortho_flat.json"), str(out)], capture_output=True,
+                           text=True, env=dict(os.environ, **env_extra))
+        assert r.returncode == 1
+        assert r.stdout.startswith("scene has:\n") and r.stdout.endswith("count of objects=1\nraytracing...")
+        assert message in r.stderr
+        assert not out.exists()
 
 
 def test_cli_scene_summary_format(tmp_path):
