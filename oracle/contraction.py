@@ -11,8 +11,8 @@ tests/test_oracle_kat.py recomputes the shipped scenes and holds them to the rec
 tests/test_gpu_parity.py holds the HIP frames to the parity criterion against BOTH builds.
 
 Neither build is the reference; together they bracket what a conforming OpenCL device may produce
-from kernel.cl as far as contraction goes (built-in sqrt / powr / division precision is a second,
-separate freedom).
+from kernel.cl as far as contraction goes (the precision of the built-ins -- division, sqrt,
+normalize, dot, powr -- is a second, separate freedom: oracle/builtin_latitude.py).
 
 Run:  python oracle/contraction.py
 """

@@ -19,13 +19,60 @@
 #include <stdlib.h>
 #include <string.h>
 
+/*
+ * The built-ins of the reference.  OpenCL C's `/`, sqrt(), normalize(), dot() and powr() are not
+ * correctly rounded by rule: the OpenCL 1.2 full profile (section 7.4) lets a device be off by
+ * 2.5 ulp for x / y, 3 ulp for sqrt, 2 + n ulp for normalize of an n-vector and 16 ulp for powr, and
+ * bounds dot() by an absolute error that a few ulp of the result stay within.  The oracle takes
+ * the correctly rounded division and sqrt of IEEE arithmetic and glibc's powf.  A second build of
+ * this file (-DMRT_ORACLE_ULP_LATITUDE, libmrt_oracle_ulp.so, oracle/Makefile) moves the result of
+ * every such operation by a whole number of ulps inside those limits -- pseudo-randomly from the
+ * result's own bits, or all up, or all down (mrt_oracle_set_ulp_mode) -- to size how far that
+ * freedom of a conforming device moves the reference's pixels (oracle/builtin_latitude.py).  That
+ * build is never the oracle.  In the oracle itself the macros below are the plain operations.
+ */
+#ifdef MRT_ORACLE_ULP_LATITUDE
+static int g_ulp_mode = 0;            /* 0 pseudo-random in [-k, k], 1 all +k, 2 all -k */
+void mrt_oracle_set_ulp_mode(int mode) { g_ulp_mode = mode; }
+static float ulp_move(float r, int k_max, uint32_t salt)
+{
+    uint32_t b;
+    memcpy(&b, &r, 4);
+    const uint32_t mag = b & 0x7FFFFFFFu;
+    if (mag == 0 || mag >= 0x7F800000u) return r;        /* zero, infinity, NaN: as they are */
+    int k;
+    if (g_ulp_mode == 1) k = k_max;
+    else if (g_ulp_mode == 2) k = -k_max;
+    else {
+        uint32_t h = (b ^ salt) * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        k = (int)(h % (uint32_t)(2 * k_max + 1)) - k_max;
+    }
+    int64_t m = (int64_t)mag + k;                        /* k ulps in magnitude; stays finite and non-zero */
+    if (m < 1) m = 1;
+    if (m > 0x7F7FFFFF) m = 0x7F7FFFFF;
+    b = (b & 0x80000000u) | (uint32_t)m;
+    memcpy(&r, &b, 4);
+    return r;
+}
+#define CL_DIV(a, b) ulp_move((a) / (b), 2, 0x9E3779B9u)
+#define CL_SQRT(x) ulp_move(sqrtf(x), 3, 0x85EBCA6Bu)
+#define CL_POWR(x, y) ulp_move(powf((x), (y)), 16, 0xC2B2AE35u)
+#define CL_BUILTIN(r, k) ulp_move((r), (k), 0x27D4EB2Fu)     /* normalize(): 2 + 3 ulp; dot(): 5 ulp */
+#else
+#define CL_DIV(a, b) ((a) / (b))
+#define CL_SQRT(x) sqrtf(x)
+#define CL_POWR(x, y) powf((x), (y))
+#define CL_BUILTIN(r, k) (r)
+#endif
+
 typedef struct { float x, y, z; } f3;
 
 static inline f3 f3_make(float x, float y, float z) { f3 r = {x, y, z}; return r; }
 static inline f3 f3_sub(f3 a, f3 b) { return f3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline f3 f3_add(f3 a, f3 b) { return f3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline f3 f3_scale(f3 a, float s) { return f3_make(a.x * s, a.y * s, a.z * s); }
-static inline f3 f3_div(f3 a, float s) { return f3_make(a.x / s, a.y / s, a.z / s); }
+static inline f3 f3_div(f3 a, float s) { return f3_make(CL_DIV(a.x, s), CL_DIV(a.y, s), CL_DIV(a.z, s)); }
 
 /* determinant3x3, kernel.cl:149-155 (cofactor expansion along the first vector). */
 static float det3(f3 s1, f3 s2, f3 s3)
@@ -53,15 +100,21 @@ static float cl_dot(f3 a, f3 b)
 }
 
 /* cl_magnitude / cl_normalize, kernel.cl:174-185.  The built-in normalize()
- * used at kernel.cl:227 is given the same definition (vector / length). */
+ * used at kernel.cl:227 is given the same definition (vector / length):
+ * cl_builtin_normalize below. */
 static float cl_magnitude(f3 a)
 {
     float m = a.x * a.x;
     m += a.y * a.y;
     m += a.z * a.z;
-    return sqrtf(m);
+    return CL_SQRT(m);
 }
 static f3 cl_normalize(f3 a) { return f3_div(a, cl_magnitude(a)); }
+static f3 cl_builtin_normalize(f3 a)
+{
+    f3 r = cl_normalize(a);
+    return f3_make(CL_BUILTIN(r.x, 5), CL_BUILTIN(r.y, 5), CL_BUILTIN(r.z, 5));
+}
 
 typedef struct {
     int is_tri;
@@ -92,14 +145,14 @@ static hit_t tri_intersect(const obj_t *tr, f3 o, f3 d, float t_upper, float t_l
     f3 s3 = d;
     f3 sol = f3_sub(tr->a, o);
     float det = det3(s1, s2, s3);
-    float bx = det3(sol, s2, s3) / det;
-    float gy = det3(s1, sol, s3) / det;
-    float tz = det3(s1, s2, sol) / det;
+    float bx = CL_DIV(det3(sol, s2, s3), det);
+    float gy = CL_DIV(det3(s1, sol, s3), det);
+    float tz = CL_DIV(det3(s1, s2, sol), det);
     if (tz < t_lower || tz > t_upper) return h;
     if (gy < 0 || gy > 1) return h;
     if (bx < 0 || bx > 1 - gy) return h;
     h.loc = f3_add(o, f3_scale(d, tz));
-    h.n = cl_normalize(cl_cross(s1, s2));
+    h.n = cl_builtin_normalize(cl_cross(s1, s2));   /* normalize(), kernel.cl:227 */
     h.hit = 1;
     h.t = tz;
     h.shininess = tr->shininess;
@@ -124,8 +177,8 @@ static hit_t circle_intersect(const obj_t *sp, f3 o, f3 d, float t_upper, float 
     if (disc < 0) return h;
     float t = -b;
     if (disc > 0) {
-        t -= sqrtf(disc);
-        t /= a;
+        t -= CL_SQRT(disc);
+        t = CL_DIV(t, a);
         if (t < t_upper && t > t_lower) {
             h.loc = f3_add(o, f3_scale(d, t));
             h.n = cl_normalize(f3_div(f3_sub(h.loc, sp->center), sp->radius));
@@ -133,7 +186,7 @@ static hit_t circle_intersect(const obj_t *sp, f3 o, f3 d, float t_upper, float 
             return h;
         }
     } else {
-        t /= a;
+        t = CL_DIV(t, a);
         if (t < t_upper && t > t_lower) {
             h.loc = f3_add(o, f3_scale(d, t));
             h.n = cl_normalize(f3_sub(h.loc, sp->center));
@@ -186,9 +239,9 @@ static f3 phong_pixel(const hit_t *h, float ka, float kd, float ks, f3 amb, f3 e
         r += h->color.x * kd * ndl;
         g += h->color.y * kd * ndl;
         b += h->color.z * kd * ndl;
-        float ndh = cl_dot(H, h->n);
+        float ndh = CL_BUILTIN(cl_dot(H, h->n), 5);   /* dot(), kernel.cl:423 */
         if (ndh < 0) ndh = 0;
-        ndh = powf(ndh, h->shininess);   /* powr(), kernel.cl:426 */
+        ndh = CL_POWR(ndh, h->shininess);   /* powr(), kernel.cl:426 */
         r += ks * ndh * lights[j].color.x;
         g += ks * ndh * lights[j].color.y;
         b += ks * ndh * lights[j].color.z;

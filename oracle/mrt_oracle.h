@@ -59,6 +59,13 @@ uint8_t mrt_oracle_to_byte(float x);
 int mrt_oracle_render(const mrt_scene *s, uint32_t row_begin, uint32_t row_end, int n_threads,
                       uint8_t *rgba, int32_t *ids, float *tval, float *rgbf);
 
+#ifdef MRT_ORACLE_ULP_LATITUDE
+/* libmrt_oracle_ulp.so only (never the oracle): how the results of the reference's built-ins are
+ * moved inside the limits OpenCL 1.2 gives a device -- 0 pseudo-randomly, 1 all up, 2 all down.
+ * Set before a render, not during one. */
+void mrt_oracle_set_ulp_mode(int mode);
+#endif
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,8 +19,10 @@ import mrt_pkg  # noqa: E402
 mrt = mrt_pkg.load()
 SO = HERE / "libmrt_oracle.so"
 SO_FMA = HERE / "libmrt_oracle_fma.so"      # same source, multiply-adds contracted (see oracle/Makefile)
+SO_ULP = HERE / "libmrt_oracle_ulp.so"      # same source, built-ins moved by whole ulps (see oracle/Makefile)
 _lib = None
 _lib_fma = None
+_lib_ulp = None
 
 
 def build():
@@ -69,10 +71,24 @@ def lib_fma():
     return _lib_fma
 
 
-def render(scene, rows=None, threads=1, want_rgbf=False, contracted=False):
+def lib_ulp(mode=0):
+    """The build whose built-ins (`/`, sqrt, normalize, dot, powr) are off by whole ulps inside
+    OpenCL 1.2's limits: NOT the oracle, only the measure of the reference's own latitude.
+    mode 0: pseudo-random offsets, 1: all up, 2: all down."""
+    global _lib_ulp
+    if _lib_ulp is None:
+        _lib_ulp = _load(SO_ULP)
+        _lib_ulp.mrt_oracle_set_ulp_mode.argtypes = [C.c_int]
+        _lib_ulp.mrt_oracle_set_ulp_mode.restype = None
+    _lib_ulp.mrt_oracle_set_ulp_mode(int(mode))
+    return _lib_ulp
+
+
+def render(scene, rows=None, threads=1, want_rgbf=False, contracted=False, ulp_mode=None):
     """Returns dict(rgba[y,x,4], ids[y,x], t[y,x], rgbf[y,x,3] or None); rows outside
     the requested range are left zero / -1.  contracted: through the build whose multiply-adds
-    are fused (lib_fma)."""
+    are fused (lib_fma); ulp_mode 0 / 1 / 2: through the build whose built-ins are moved by whole
+    ulps (lib_ulp)."""
     st = scene.struct
     h, w = st.yres, st.xres
     r0, r1 = (0, h) if rows is None else rows
@@ -80,7 +96,9 @@ def render(scene, rows=None, threads=1, want_rgbf=False, contracted=False):
     ids = np.full((h, w), -1, np.int32)
     t = np.full((h, w), -1.0, np.float32)
     rgbf = np.zeros((h, w, 3), np.float32) if want_rgbf else None
-    rc = (lib_fma() if contracted else lib()).mrt_oracle_render(C.byref(st), r0, r1, threads, rgba.ctypes.data, ids.ctypes.data,
+    assert not (contracted and ulp_mode is not None)
+    L = lib_ulp(ulp_mode) if ulp_mode is not None else (lib_fma() if contracted else lib())
+    rc = L.mrt_oracle_render(C.byref(st), r0, r1, threads, rgba.ctypes.data, ids.ctypes.data,
                                  t.ctypes.data, rgbf.ctypes.data if want_rgbf else None)
     if rc != 0:
         raise RuntimeError("mrt_oracle_render rejected the scene")
