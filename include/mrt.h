@@ -297,17 +297,18 @@ int mrt_render_bands_device(mrt_ctx *ctx, uint32_t band_rows, uint32_t rank, uin
  * Not allocating is all it promises.  HIP graph capture is NOT supported: on a
  * stream that is capturing (hipStreamBeginCapture) this call -- like every other
  * entry point that takes a stream -- fails with MRT_ERR_INVALID before it
- * enqueues anything, and the capture stays valid.  Replaying a recorded frame
- * ended in a GPU memory fault each of the three times it was tried (with the
- * default and with the MRT_FLAG_FULL_TEST kernels, through torch.cuda.graph and
- * through hipStreamBeginCapture directly).  What such a recording holds that
- * ordinary captured work may not -- a memset node on the fixed array, which is
- * a __device__ symbol and not a hipMalloc'ed buffer, and kernels that take a
- * 328-byte structure by value -- replays correctly when recorded on its own
- * (tools/graph_probe.hip), and the nodes of a recorded frame hold the grid,
- * the block and, byte for byte, the arguments of the eager call
- * (tools/graph_frame_probe.cpp on a -DMRT_ALLOW_CAPTURE build): the cause is
- * not in what the library records, and a replay was not risked again.
+ * enqueues anything, and the capture stays valid.  What is known about replay
+ * (diagnostic -DMRT_ALLOW_CAPTURE builds only): a recorded frame -- a memset
+ * node on the fixed array, trace kernel, shading kernel, in a chain -- holds
+ * the grid, the block and, byte for byte, the arguments of the eager call, and
+ * replayed from a plain C++ program it writes the eager frame's bytes, on the
+ * HIP 7.2 runtime and on the 7.0 runtime the PyTorch wheel brings alike
+ * (tools/graph_frame_probe.cpp --replay; tools/graph_probe.hip for the parts on
+ * their own).  Replayed inside a Python process in which PyTorch has started
+ * that same runtime, the first hipGraphLaunch ends in hipErrorIllegalAddress
+ * and leaves the GPU faulted (four times out of four, torch.cuda.graph or
+ * hipStreamBeginCapture alike).  Why was not taken apart further, every
+ * attempt costs a GPU; hence the refusal, everywhere.
  * No counterpart in the reference, which allocates in every stage call
  * (CLHelpers.hpp:93-104). */
 #define MRT_NOALLOC_MAX_KEYS (8u * 1024u * 1024u)
