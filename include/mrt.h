@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 7
+#define MRT_ABI_VERSION 8
 
 typedef enum mrt_status {
     MRT_OK = 0,
@@ -49,7 +49,9 @@ typedef enum mrt_status {
     MRT_ERR_NO_SCENE = -4,     /* render called before mrt_set_scene           */
     MRT_ERR_TOO_LARGE = -5,    /* size beyond a documented limit               */
     MRT_ERR_IO = -6,           /* file could not be read / written             */
-    MRT_ERR_PARSE = -7         /* scene file rejected (message has the reason) */
+    MRT_ERR_PARSE = -7,        /* scene file rejected (message has the reason) */
+    MRT_ERR_NO_MEMORY = -8     /* host memory could not be allocated (the C++ runtime's
+                                  std::bad_alloc, caught at the boundary)      */
 } mrt_status;
 
 enum { MRT_PROJ_ORTHO = 0, MRT_PROJ_PERSP = 1 };

@@ -27,7 +27,7 @@ RESERVED_FLAG_BITS = (1 << 2) | (1 << 4) | (1 << 30)          # mrt_create refus
 KERNEL_TRACE, KERNEL_TRACE_BLOCK, KERNEL_CULL, KERNEL_FULL, KERNEL_GRID, KERNEL_TRACE_WIDE = 0, 1, 2, 3, 4, 5    # mrt_stats.kernel
 ACCEL_GRID, ACCEL_TILE_CULL, ACCEL_BLOCK_REJECT = 0, 1, 2                                 # mrt_accel_config.method
 ACCEL_METHODS = {"grid": ACCEL_GRID, "cull": ACCEL_TILE_CULL, "block": ACCEL_BLOCK_REJECT}
-ABI_VERSION = 7
+ABI_VERSION = 8
 PROJ_ORTHO, PROJ_PERSP = 0, 1
 SHADER_FLAT, SHADER_PHONG = 0, 1
 

@@ -23,6 +23,7 @@
 // end in the reference arithmetic for the surviving pairs, merged by (t, id)
 // keys, so ids, t and bytes equal the brute-force context's.
 #include "mrt.h"
+#include "mrt_guard.hpp"
 #include "mrt_internal.hpp"
 #include "mrt_kernels.hpp"
 #include "mrt_tile_tests.hpp"
@@ -578,7 +579,7 @@ extern "C" {
 
 const char* mrt_accel_last_error(const mrt_accel* a) { return a ? a->err.c_str() : g_accel_create_err.c_str(); }
 
-int mrt_accel_create(const mrt_accel_config* cfg, mrt_accel** out) {
+int mrt_accel_create(const mrt_accel_config* cfg, mrt_accel** out) try {
     if (!out) return afail(nullptr, MRT_ERR_INVALID, "out is NULL");
     *out = nullptr;
     const uint32_t method = cfg ? cfg->method : (uint32_t)MRT_ACCEL_GRID;
@@ -617,7 +618,7 @@ int mrt_accel_create(const mrt_accel_config* cfg, mrt_accel** out) {
     }
     *out = a;
     return MRT_OK;
-}
+} MRT_GUARD((void)afail(nullptr, code_, what_))
 
 void mrt_accel_destroy(mrt_accel* a) {
     if (!a) return;
@@ -645,7 +646,7 @@ void mrt_accel_destroy(mrt_accel* a) {
 
 uint32_t mrt_accel_method(const mrt_accel* a) { return a ? a->method : 0u; }
 
-int mrt_accel_set_scene(mrt_accel* a, const mrt_scene* scene) {
+int mrt_accel_set_scene(mrt_accel* a, const mrt_scene* scene) try {
     if (!a) return MRT_ERR_INVALID;
     a->have_scene = false;
     int rc = mrt_set_scene(a->base, scene);
@@ -659,9 +660,9 @@ int mrt_accel_set_scene(mrt_accel* a, const mrt_scene* scene) {
     }
     a->have_scene = true;
     return MRT_OK;
-}
+} MRT_GUARD((void)afail(a, code_, what_))
 
-int mrt_accel_set_camera(mrt_accel* a, const mrt_camera* camera) {
+int mrt_accel_set_camera(mrt_accel* a, const mrt_camera* camera) try {
     if (!a) return MRT_ERR_INVALID;
     if (!a->have_scene) return afail(a, MRT_ERR_NO_SCENE, "mrt_accel_set_scene has not succeeded on this handle");
     a->have_scene = false;
@@ -685,10 +686,10 @@ int mrt_accel_set_camera(mrt_accel* a, const mrt_camera* camera) {
     }
     a->have_scene = true;
     return MRT_OK;
-}
+} MRT_GUARD((void)afail(a, code_, what_))
 
 int mrt_accel_render_bands_device(mrt_accel* a, uint32_t band_rows, uint32_t rank, uint32_t world, void* dev_out,
-                                  size_t dev_out_bytes, void* hip_stream, mrt_accel_stats* stats) {
+                                  size_t dev_out_bytes, void* hip_stream, mrt_accel_stats* stats) try {
     if (!a) return MRT_ERR_INVALID;
     if (!a->have_scene) return afail(a, MRT_ERR_NO_SCENE, "mrt_accel_set_scene has not succeeded on this handle");
     if (a->method != MRT_ACCEL_GRID) {
@@ -717,9 +718,9 @@ int mrt_accel_render_bands_device(mrt_accel* a, uint32_t band_rows, uint32_t ran
         rc = fill_grid_stats(a, stats, rows);
     }
     return rc;
-}
+} MRT_GUARD((void)afail(a, code_, what_))
 
-int mrt_accel_render_debug(mrt_accel* a, uint8_t* host_out, int32_t* ids, float* t, mrt_accel_stats* stats) {
+int mrt_accel_render_debug(mrt_accel* a, uint8_t* host_out, int32_t* ids, float* t, mrt_accel_stats* stats) try {
     if (!a) return MRT_ERR_INVALID;
     if (!a->have_scene) return afail(a, MRT_ERR_NO_SCENE, "mrt_accel_set_scene has not succeeded on this handle");
     if (!host_out && !ids && !t) return afail(a, MRT_ERR_INVALID, "no output requested");
@@ -766,12 +767,12 @@ int mrt_accel_render_debug(mrt_accel* a, uint8_t* host_out, int32_t* ids, float*
     local.frame.download_ms = dms;
     if (stats) *stats = local;
     return MRT_OK;
-}
+} MRT_GUARD((void)afail(a, code_, what_))
 
-int mrt_accel_render_rgba8(mrt_accel* a, uint8_t* host_out, mrt_accel_stats* stats) {
+int mrt_accel_render_rgba8(mrt_accel* a, uint8_t* host_out, mrt_accel_stats* stats) try {
     if (!a) return MRT_ERR_INVALID;
     if (!host_out) return afail(a, MRT_ERR_INVALID, "host_out is NULL");
     return mrt_accel_render_debug(a, host_out, nullptr, nullptr, stats);
-}
+} MRT_GUARD((void)afail(a, code_, what_))
 
 }  // extern "C"

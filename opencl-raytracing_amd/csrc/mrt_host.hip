@@ -8,6 +8,7 @@
 // records on the GPU (mrt_set_camera, no copies, no waiting) and a frame is one
 // or two kernel launches.
 #include "mrt.h"
+#include "mrt_guard.hpp"
 #include "mrt_internal.hpp"
 #include "mrt_kernels.hpp"
 
@@ -631,7 +632,7 @@ int mrt_abi_version(void) { return MRT_ABI_VERSION; }
 
 const char* mrt_last_error(const mrt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
-int mrt_create(const mrt_config* cfg, mrt_ctx** out) {
+int mrt_create(const mrt_config* cfg, mrt_ctx** out) try {
     if (!out) return fail(nullptr, MRT_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (cfg && (cfg->flags & MRT_IFLAG_MASK))
@@ -640,9 +641,9 @@ int mrt_create(const mrt_config* cfg, mrt_ctx** out) {
     if (cfg && (cfg->flags & MRT_FLAG_TRACE_NARROW) && (cfg->flags & MRT_FLAG_TRACE_WIDE))
         return fail(nullptr, MRT_ERR_INVALID, "MRT_FLAG_TRACE_NARROW and MRT_FLAG_TRACE_WIDE exclude each other");
     return mrt_create_internal_(cfg, out);
-}
+} MRT_GUARD((void)fail(nullptr, code_, what_))
 
-int mrt_create_internal_(const mrt_config* cfg, mrt_ctx** out) {
+int mrt_create_internal_(const mrt_config* cfg, mrt_ctx** out) try {
     if (!out) return fail(nullptr, MRT_ERR_INVALID, "out is NULL");
     *out = nullptr;
     // MRT_STATS=1: where the start-up of the first context of a process goes, one JSON line on stderr
@@ -664,6 +665,10 @@ int mrt_create_internal_(const mrt_config* cfg, mrt_ctx** out) {
     }
     if (dev >= count) return fail(nullptr, MRT_ERR_NO_DEVICE, "device ordinal out of range");
     mrt_ctx* ctx = new mrt_ctx();
+    struct Owner {                                     // an exception on the way out must not leak the ctx
+        mrt_ctx* c;
+        ~Owner() { if (c) mrt_destroy(c); }
+    } owner{ctx};
     ctx->device = dev;
     ctx->flags = cfg ? cfg->flags : 0;
     if (const char* force = std::getenv("MRT_FORCE_SLICES")) {
@@ -673,6 +678,7 @@ int mrt_create_internal_(const mrt_config* cfg, mrt_ctx** out) {
     }
     auto bail = [&](const char* what, hipError_t err) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+        owner.c = nullptr;
         mrt_destroy(ctx);
         return fail(nullptr, MRT_ERR_HIP, msg);
     };
@@ -700,9 +706,10 @@ int mrt_create_internal_(const mrt_config* cfg, mrt_ctx** out) {
         std::fprintf(stderr, "{\"mrt_create\": {\"runtime_start_ms\": %.3f, \"first_stream_ms\": %.3f, \"first_malloc_ms\": %.3f, "
                              "\"code_object_load_ms\": %.3f, \"total_ms\": %.3f}}\n",
                      runtime_ms, stream_ms, malloc_ms, code_object_ms, ms_since(t0));
+    owner.c = nullptr;
     *out = ctx;
     return MRT_OK;
-}
+} MRT_GUARD((void)fail(nullptr, code_, what_))
 
 void mrt_destroy(mrt_ctx* ctx) {
     if (!ctx) return;
@@ -853,7 +860,7 @@ static int rebuild_view(mrt_ctx* ctx, bool may_allocate) {
     return MRT_OK;
 }
 
-int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
+int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) try {
     if (!ctx) return MRT_ERR_INVALID;
     int rc = check_scene(ctx, s);
     if (rc != MRT_OK) return rc;
@@ -924,9 +931,9 @@ int mrt_set_scene(mrt_ctx* ctx, const mrt_scene* s) {
     ctx->upload_ms = ms;
     ctx->have_scene = true;
     return MRT_OK;
-}
+} MRT_GUARD((void)fail(ctx, code_, what_))
 
-int mrt_set_camera(mrt_ctx* ctx, const mrt_camera* cam) {
+int mrt_set_camera(mrt_ctx* ctx, const mrt_camera* cam) try {
     if (!ctx) return MRT_ERR_INVALID;
     if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
     if (!cam) return fail(ctx, MRT_ERR_INVALID, "camera is NULL");
@@ -950,9 +957,9 @@ int mrt_set_camera(mrt_ctx* ctx, const mrt_camera* cam) {
     if (rc != MRT_OK) return rc;
     ctx->have_scene = true;
     return MRT_OK;
-}
+} MRT_GUARD((void)fail(ctx, code_, what_))
 
-int mrt_synchronize(mrt_ctx* ctx) {
+int mrt_synchronize(mrt_ctx* ctx) try {
     if (!ctx) return MRT_ERR_INVALID;
     ENTER_DEVICE(ctx);
     if (ctx->records_pending) HIP_TRY(ctx, hipEventSynchronize(ctx->records_ready));
@@ -961,7 +968,7 @@ int mrt_synchronize(mrt_ctx* ctx) {
     ctx->frame_pending = false;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MRT_OK;
-}
+} MRT_GUARD((void)fail(ctx, code_, what_))
 
 uint32_t mrt_band_rows(uint32_t yres, uint32_t band_rows, uint32_t rank, uint32_t world) {
     if (band_rows == 0 || world == 0 || rank >= world) return 0;
@@ -992,7 +999,7 @@ uint32_t mrt_balanced_band_rows(uint32_t yres, uint32_t world) {
 }
 
 int mrt_render_bands_device(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world,
-                            void* dev_out, size_t dev_out_bytes, void* hip_stream, mrt_stats* stats) {
+                            void* dev_out, size_t dev_out_bytes, void* hip_stream, mrt_stats* stats) try {
     if (!ctx) return MRT_ERR_INVALID;
     if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
     if (band_rows == 0 || world == 0 || rank >= world) return fail(ctx, MRT_ERR_INVALID, "bad band partition");
@@ -1011,10 +1018,10 @@ int mrt_render_bands_device(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uin
         rc = fill_stats(ctx, stats, rows);
     }
     return rc;
-}
+} MRT_GUARD((void)fail(ctx, code_, what_))
 
 int mrt_render_bands_device_noalloc(mrt_ctx* ctx, uint32_t band_rows, uint32_t rank, uint32_t world,
-                                    void* dev_out, size_t dev_out_bytes, void* hip_stream) {
+                                    void* dev_out, size_t dev_out_bytes, void* hip_stream) try {
     if (!ctx) return MRT_ERR_INVALID;
     if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
     if (band_rows == 0 || world == 0 || rank >= world) return fail(ctx, MRT_ERR_INVALID, "bad band partition");
@@ -1035,9 +1042,9 @@ int mrt_render_bands_device_noalloc(mrt_ctx* ctx, uint32_t band_rows, uint32_t r
     planes.key = ctx->scratch_keys;
     planes.key_capacity = MRT_NOALLOC_MAX_KEYS;
     return launch_frame(ctx, band_rows, rank, world, (uint32_t*)dev_out, (hipStream_t)hip_stream, false, planes);
-}
+} MRT_GUARD((void)fail(ctx, code_, what_))
 
-int mrt_render_debug(mrt_ctx* ctx, uint8_t* host_out, int32_t* ids, float* t, mrt_stats* stats) {
+int mrt_render_debug(mrt_ctx* ctx, uint8_t* host_out, int32_t* ids, float* t, mrt_stats* stats) try {
     if (!ctx) return MRT_ERR_INVALID;
     if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
     if (!host_out && !ids && !t) return fail(ctx, MRT_ERR_INVALID, "no output requested");
@@ -1076,10 +1083,10 @@ int mrt_render_debug(mrt_ctx* ctx, uint8_t* host_out, int32_t* ids, float* t, mr
     local.download_ms = dms;
     if (stats) *stats = local;
     return MRT_OK;
-}
+} MRT_GUARD((void)fail(ctx, code_, what_))
 
 int mrt_render_rgba8_rows(mrt_ctx* ctx, uint8_t* host_out, uint32_t strip_rows, mrt_rows_ready_fn ready, void* user,
-                          mrt_stats* stats) {
+                          mrt_stats* stats) try {
     if (!ctx) return MRT_ERR_INVALID;
     if (!ctx->have_scene) return fail(ctx, MRT_ERR_NO_SCENE, "mrt_set_scene has not succeeded on this context");
     if (!host_out) return fail(ctx, MRT_ERR_INVALID, "host_out is NULL");
@@ -1147,15 +1154,15 @@ int mrt_render_rgba8_rows(mrt_ctx* ctx, uint8_t* host_out, uint32_t strip_rows, 
         rc = fill_stats(ctx, stats, yres);
     }
     return rc;
-}
+} MRT_GUARD((void)fail(ctx, code_, what_))
 
-int mrt_render_rgba8(mrt_ctx* ctx, uint8_t* host_out, mrt_stats* stats) {
+int mrt_render_rgba8(mrt_ctx* ctx, uint8_t* host_out, mrt_stats* stats) try {
     if (!ctx) return MRT_ERR_INVALID;
     if (!host_out) return fail(ctx, MRT_ERR_INVALID, "host_out is NULL");
     return mrt_render_debug(ctx, host_out, nullptr, nullptr, stats);
-}
+} MRT_GUARD((void)fail(ctx, code_, what_))
 
-int mrt_host_alloc(size_t bytes, void** out) {
+int mrt_host_alloc(size_t bytes, void** out) try {
     if (!out) return MRT_ERR_INVALID;
     *out = nullptr;
     void* p = nullptr;
@@ -1165,7 +1172,7 @@ int mrt_host_alloc(size_t bytes, void** out) {
     }
     *out = p;
     return MRT_OK;
-}
+} MRT_GUARD((void)fail(nullptr, code_, what_))
 
 void mrt_host_free(void* p) {
     if (p) (void)hipHostFree(p);

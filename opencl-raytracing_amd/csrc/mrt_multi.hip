@@ -19,6 +19,7 @@
 // pass over the image on the host.  RCCL is loaded with dlopen the first time
 // it is asked for, so that the library has no load-time dependency on it.
 #include "mrt.h"
+#include "mrt_guard.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -193,7 +194,7 @@ void mrt_multi_destroy(mrt_multi* m) {
     delete m;
 }
 
-int mrt_multi_create(const mrt_multi_config* cfg, mrt_multi** out) {
+int mrt_multi_create(const mrt_multi_config* cfg, mrt_multi** out) try {
     if (!out) return mfail(nullptr, MRT_ERR_INVALID, "out is NULL");
     *out = nullptr;
     int count = 0;
@@ -267,11 +268,11 @@ int mrt_multi_create(const mrt_multi_config* cfg, mrt_multi** out) {
     }
     *out = m;
     return MRT_OK;
-}
+} MRT_GUARD((void)mfail(nullptr, code_, what_))
 
 uint32_t mrt_multi_world(const mrt_multi* m) { return m ? (uint32_t)m->ranks.size() : 0u; }
 
-int mrt_multi_set_scene(mrt_multi* m, const mrt_scene* scene) {
+int mrt_multi_set_scene(mrt_multi* m, const mrt_scene* scene) try {
     if (!m) return MRT_ERR_INVALID;
     if (!scene) return mfail(m, MRT_ERR_INVALID, "scene is NULL");
     m->have_scene = false;
@@ -286,9 +287,9 @@ int mrt_multi_set_scene(mrt_multi* m, const mrt_scene* scene) {
     if (rc != MRT_OK) return rc;
     m->have_scene = true;
     return MRT_OK;
-}
+} MRT_GUARD((void)mfail(m, code_, what_))
 
-int mrt_multi_set_camera(mrt_multi* m, const mrt_camera* camera) {
+int mrt_multi_set_camera(mrt_multi* m, const mrt_camera* camera) try {
     if (!m) return MRT_ERR_INVALID;
     if (!m->have_scene) return mfail(m, MRT_ERR_NO_SCENE, "mrt_multi_set_scene has not succeeded");
     if (!camera) return mfail(m, MRT_ERR_INVALID, "camera is NULL");
@@ -307,14 +308,14 @@ int mrt_multi_set_camera(mrt_multi* m, const mrt_camera* camera) {
     if (rc != MRT_OK) return rc;
     m->have_scene = true;
     return MRT_OK;
-}
+} MRT_GUARD((void)mfail(m, code_, what_))
 
-int mrt_multi_render_rgba8(mrt_multi* m, uint8_t* host_out, mrt_multi_stats* stats) {
+int mrt_multi_render_rgba8(mrt_multi* m, uint8_t* host_out, mrt_multi_stats* stats) try {
     return mrt_multi_render_rgba8_rows(m, host_out, nullptr, nullptr, stats);
-}
+} MRT_GUARD((void)mfail(m, code_, what_))
 
 int mrt_multi_render_rgba8_rows(mrt_multi* m, uint8_t* host_out, mrt_rows_ready_fn ready, void* user,
-                                mrt_multi_stats* stats) {
+                                mrt_multi_stats* stats) try {
     if (!m) return MRT_ERR_INVALID;
     if (!m->have_scene) return mfail(m, MRT_ERR_NO_SCENE, "mrt_multi_set_scene has not succeeded");
     if (!host_out) return mfail(m, MRT_ERR_INVALID, "host_out is NULL");
@@ -430,7 +431,7 @@ int mrt_multi_render_rgba8_rows(mrt_multi* m, uint8_t* host_out, mrt_rows_ready_
         stats->gather = m->gather;
     }
     return MRT_OK;
-}
+} MRT_GUARD((void)mfail(m, code_, what_))
 
 uint32_t mrt_multi_gather(const mrt_multi* m) { return m ? m->gather : 0u; }
 const char* mrt_multi_note(const mrt_multi* m) { return m ? m->note.c_str() : ""; }

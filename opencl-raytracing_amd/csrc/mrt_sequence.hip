@@ -8,6 +8,7 @@
 // directly except the slots' streams; the frames are mrt_set_camera +
 // mrt_render_bands_device on the slot's context.
 #include "mrt.h"
+#include "mrt_guard.hpp"
 #include "mrt_internal.hpp"
 
 #include <hip/hip_runtime.h>
@@ -92,7 +93,7 @@ void mrt_sequence_destroy(mrt_sequence* q) {
     delete q;
 }
 
-int mrt_sequence_create(const mrt_sequence_config* cfg, mrt_sequence** out) {
+int mrt_sequence_create(const mrt_sequence_config* cfg, mrt_sequence** out) try {
     if (!out) return qfail(nullptr, MRT_ERR_INVALID, "out is NULL");
     *out = nullptr;
     uint32_t n = cfg ? cfg->in_flight : 0u;
@@ -142,9 +143,9 @@ int mrt_sequence_create(const mrt_sequence_config* cfg, mrt_sequence** out) {
     }
     *out = q;
     return MRT_OK;
-}
+} MRT_GUARD((void)qfail(nullptr, code_, what_))
 
-int mrt_sequence_wait(mrt_sequence* q) {
+int mrt_sequence_wait(mrt_sequence* q) try {
     if (!q) return MRT_ERR_INVALID;
     KeepDevice keep;
     hipError_t e = hipSetDevice(q->device);
@@ -153,9 +154,9 @@ int mrt_sequence_wait(mrt_sequence* q) {
     if (e == hipSuccess && q->copy_stream) e = hipStreamSynchronize(q->copy_stream);
     if (e != hipSuccess) return qfail(q, MRT_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return MRT_OK;
-}
+} MRT_GUARD((void)qfail(q, code_, what_))
 
-int mrt_sequence_set_scene(mrt_sequence* q, const mrt_scene* scene) {
+int mrt_sequence_set_scene(mrt_sequence* q, const mrt_scene* scene) try {
     if (!q) return MRT_ERR_INVALID;
     if (!scene) return qfail(q, MRT_ERR_INVALID, "scene is NULL");
     q->have_scene = false;
@@ -175,7 +176,7 @@ int mrt_sequence_set_scene(mrt_sequence* q, const mrt_scene* scene) {
     q->view_serial = 0;
     q->have_scene = true;
     return MRT_OK;
-}
+} MRT_GUARD((void)qfail(q, code_, what_))
 
 // The slot of the next frame, with `view` (NULL = as before) taken: a new view counts only once
 // a slot has accepted it.
@@ -198,7 +199,7 @@ static int next_slot(mrt_sequence* q, const mrt_camera* view, Slot** out) {
 }
 
 int mrt_sequence_submit(mrt_sequence* q, const mrt_camera* view, uint32_t band_rows, uint32_t rank,
-                        uint32_t world, void* dev_out, size_t dev_out_bytes, void** frame_stream) {
+                        uint32_t world, void* dev_out, size_t dev_out_bytes, void** frame_stream) try {
     if (!q) return MRT_ERR_INVALID;
     if (frame_stream) *frame_stream = nullptr;
     if (!q->have_scene) return qfail(q, MRT_ERR_NO_SCENE, "mrt_sequence_set_scene has not succeeded");
@@ -210,9 +211,9 @@ int mrt_sequence_submit(mrt_sequence* q, const mrt_camera* view, uint32_t band_r
     if (frame_stream) *frame_stream = (void*)s->stream;
     ++q->next;
     return MRT_OK;
-}
+} MRT_GUARD((void)qfail(q, code_, what_))
 
-int mrt_sequence_submit_host(mrt_sequence* q, const mrt_camera* view, uint8_t* host_out) {
+int mrt_sequence_submit_host(mrt_sequence* q, const mrt_camera* view, uint8_t* host_out) try {
     if (!q) return MRT_ERR_INVALID;
     if (!q->have_scene) return qfail(q, MRT_ERR_NO_SCENE, "mrt_sequence_set_scene has not succeeded");
     if (!host_out) return qfail(q, MRT_ERR_INVALID, "host_out is NULL");
@@ -266,6 +267,6 @@ int mrt_sequence_submit_host(mrt_sequence* q, const mrt_camera* view, uint8_t* h
     ++q->host_next;
     ++q->next;
     return MRT_OK;
-}
+} MRT_GUARD((void)qfail(q, code_, what_))
 
 }  // extern "C"

@@ -9,6 +9,7 @@
 // trade speed for the reference's exact call shape.  Arithmetic is the shared
 // exact code of mrt_device.hpp.
 #include "mrt.h"
+#include "mrt_guard.hpp"
 #include "mrt_device.hpp"
 
 #include <hip/hip_runtime.h>
@@ -622,7 +623,7 @@ int shade_common(mrt_ctx* ctx, const mrt_cl_intersect* xsects, int n, mrt_cl_rgb
 extern "C" {
 
 int mrt_stage_uv(mrt_ctx* ctx, const mrt_cl_float3* positions, const mrt_cl_vp* viewport, int n,
-                 mrt_cl_float2* uv_out) {
+                 mrt_cl_float2* uv_out) try {
     RestoreDevice restore_device;
     int rc = begin(ctx, n, positions, uv_out);
     if (rc != MRT_OK) return rc;
@@ -639,20 +640,20 @@ int mrt_stage_uv(mrt_ctx* ctx, const mrt_cl_float3* positions, const mrt_cl_vp* 
     STAGE_TRY(hipGetLastError());
     STAGE_COPY(uv_out, d_uv.p, (size_t)n * 8, hipMemcpyDeviceToHost);
     return MRT_OK;
-}
+} MRT_GUARD((void)mrt_stage_set_error_(ctx, code_, what_))
 
 int mrt_stage_ortho_viewrays(mrt_ctx* ctx, const mrt_cl_cam* camera, const mrt_cl_float2* uv, int n,
-                             mrt_cl_ray* rays_out) {
+                             mrt_cl_ray* rays_out) try {
     return rays_common(ctx, camera, uv, n, 0.0f, rays_out, false);
-}
+} MRT_GUARD((void)mrt_stage_set_error_(ctx, code_, what_))
 
 int mrt_stage_persp_viewrays(mrt_ctx* ctx, const mrt_cl_cam* camera, const mrt_cl_float2* uv, int n,
-                             float focal_length, mrt_cl_ray* rays_out) {
+                             float focal_length, mrt_cl_ray* rays_out) try {
     return rays_common(ctx, camera, uv, n, focal_length, rays_out, true);
-}
+} MRT_GUARD((void)mrt_stage_set_error_(ctx, code_, what_))
 
 int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_objects, const mrt_cl_ray* rays,
-                        int n_rays, float t_upper_bound, float t_lower_bound, mrt_cl_intersect* out) {
+                        int n_rays, float t_upper_bound, float t_lower_bound, mrt_cl_intersect* out) try {
     RestoreDevice restore_device;
     int rc = begin(ctx, n_rays, rays, out);
     if (rc != MRT_OK) return rc;
@@ -793,19 +794,19 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
         }
     }
     return MRT_OK;
-}
+} MRT_GUARD((void)mrt_stage_set_error_(ctx, code_, what_))
 
 double mrt_stage_last_kernel_ms(const mrt_ctx* ctx) { return ctx ? mrt_stage_get_kernel_ms_(ctx) : 0.0; }
 
 int mrt_stage_flat_shader(mrt_ctx* ctx, const mrt_cl_intersect* xsects, int n, mrt_cl_rgb background,
-                          mrt_cl_rgb* out) {
+                          mrt_cl_rgb* out) try {
     return shade_common(ctx, xsects, n, background, nullptr, nullptr, nullptr, 0, out, true);
-}
+} MRT_GUARD((void)mrt_stage_set_error_(ctx, code_, what_))
 
 int mrt_stage_phong_shader(mrt_ctx* ctx, const mrt_cl_intersect* xsects, const mrt_cl_phong* phong, int n,
                            mrt_cl_rgb background, const mrt_cl_cam* camera, const mrt_cl_light* lights,
-                           int n_lights, mrt_cl_rgb* out) {
+                           int n_lights, mrt_cl_rgb* out) try {
     return shade_common(ctx, xsects, n, background, phong, camera, lights, n_lights, out, false);
-}
+} MRT_GUARD((void)mrt_stage_set_error_(ctx, code_, what_))
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 // complete (mrt_png_stream_*): a stripe is deflated as soon as its rows are in,
 // while the GPUs still render and copy the rest.
 #include "mrt.h"
+#include "mrt_guard.hpp"
 
 #include <zlib.h>
 
@@ -125,7 +126,11 @@ void stream_worker(mrt_png_stream* s) {
         const uint32_t k = s->runnable.front();
         s->runnable.pop_front();
         lock.unlock();
-        deflate_stripe(s->rgba, s->xres, s->stripes[k], k + 1 == (uint32_t)s->stripes.size());
+        try {
+            deflate_stripe(s->rgba, s->xres, s->stripes[k], k + 1 == (uint32_t)s->stripes.size());
+        } catch (...) {                                         // out of memory: the stripe stays "not ok", the file is not written
+            s->stripes[k].ok = false;
+        }
         lock.lock();
         ++s->done;
         s->cv_done.notify_all();
@@ -176,7 +181,9 @@ extern "C" int mrt_png_stream_begin(const char* path, const uint8_t* rgba, uint3
     if (!out) return MRT_ERR_INVALID;
     *out = nullptr;
     if (!path || !rgba || xres == 0 || yres == 0) return MRT_ERR_INVALID;
-    mrt_png_stream* s = new mrt_png_stream();
+    mrt_png_stream* s = nullptr;
+    try {
+    s = new mrt_png_stream();
     s->path = path;
     s->rgba = rgba;
     s->xres = xres;
@@ -201,11 +208,25 @@ extern "C" int mrt_png_stream_begin(const char* path, const uint8_t* rgba, uint3
     }
     const unsigned n_threads = std::max(1u, std::min<unsigned>(std::min(hw ? hw : 1u, cap), n_stripes));
     for (unsigned t = 0; t < n_threads; ++t) s->pool.emplace_back(stream_worker, s);
+    } catch (...) {
+        // no memory for the tables, or a thread that could not be started: the threads that did
+        // start are told to leave, and there is no stream
+        if (s) {
+            {
+                std::lock_guard<std::mutex> lock(s->mu);
+                s->closing = true;
+            }
+            s->cv_work.notify_all();
+            for (auto& th : s->pool) th.join();
+            delete s;
+        }
+        return mrt::on_exception([](int, const char*) {});
+    }
     *out = s;
     return MRT_OK;
 }
 
-extern "C" int mrt_png_stream_rows(mrt_png_stream* s, uint32_t row_begin, uint32_t row_end) {
+extern "C" int mrt_png_stream_rows(mrt_png_stream* s, uint32_t row_begin, uint32_t row_end) try {
     if (!s || row_begin > row_end || row_end > s->yres) return MRT_ERR_INVALID;
     std::lock_guard<std::mutex> lock(s->mu);
     for (uint32_t r = row_begin; r < row_end;) {                            // a row reported twice: nothing is taken
@@ -226,9 +247,9 @@ extern "C" int mrt_png_stream_rows(mrt_png_stream* s, uint32_t row_begin, uint32
         r = upto;
     }
     return MRT_OK;
-}
+} MRT_GUARD()
 
-extern "C" int mrt_png_stream_end(mrt_png_stream* s) {
+extern "C" int mrt_png_stream_end(mrt_png_stream* s) try {
     if (!s) return MRT_ERR_INVALID;
     int rc = MRT_OK;
     {
@@ -248,13 +269,13 @@ extern "C" int mrt_png_stream_end(mrt_png_stream* s) {
     if (rc == MRT_OK && !write_file(*s)) rc = MRT_ERR_IO;
     delete s;
     return rc;
-}
+} MRT_GUARD()
 
-extern "C" int mrt_write_png_rgb(const char* path, const uint8_t* rgba, uint32_t xres, uint32_t yres) {
+extern "C" int mrt_write_png_rgb(const char* path, const uint8_t* rgba, uint32_t xres, uint32_t yres) try {
     mrt_png_stream* s = nullptr;
     int rc = mrt_png_stream_begin(path, rgba, xres, yres, &s);
     if (rc != MRT_OK) return rc;
     rc = mrt_png_stream_rows(s, 0, yres);
     const int rc_end = mrt_png_stream_end(s);
     return rc != MRT_OK ? rc : rc_end;
-}
+} MRT_GUARD()

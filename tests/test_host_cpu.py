@@ -313,3 +313,29 @@ def test_png_stream_writes_the_same_file(mrt, tmp_path):
     with pytest.raises(mrt.MrtError):
         s.rows(0, h + 1)
     s.end()
+
+
+def test_no_cpp_exception_leaves_the_library(tmp_path):
+    """include/mrt.h promises a C boundary.  A process whose address space is capped asks for a PNG
+    stream whose stripe table alone needs gigabytes: the failed allocation inside the library must
+    come back as MRT_ERR_NO_MEMORY (-8), not as an uncaught std::bad_alloc that aborts the caller."""
+    code = f"""
+import ctypes as C, resource, sys
+sys.path.insert(0, {str(ROOT)!r})
+import mrt_pkg
+mrt_pkg.load()
+from opencl_raytracing_amd import capi
+L = capi.lib()
+resource.setrlimit(resource.RLIMIT_AS, (3 << 30, 3 << 30))
+L.mrt_png_stream_begin.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+L.mrt_png_stream_begin.restype = C.c_int
+one = (C.c_uint8 * 4)()
+h = C.c_void_p()
+# 65536 pixels per row: 21 rows per stripe, 2^31 rows: a hundred million stripes
+rc = L.mrt_png_stream_begin({str(tmp_path / 'never.png')!r}.encode(), one, 65536, 0x7FFFFFFF, C.byref(h))
+print("rc", rc, "handle", h.value)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-400:]
+    assert "rc -8 handle None" in r.stdout, (r.stdout, r.stderr[-400:])
+    assert not (tmp_path / "never.png").exists()
