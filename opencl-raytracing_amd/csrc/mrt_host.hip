@@ -139,6 +139,8 @@ struct mrt_ctx {
     void* stage_buf[kStageSlots] = {};
     size_t stage_cap[kStageSlots] = {};
     double stage_kernel_ms = 0.0;            // device time of the kernels of the last mrt_stage_intersect
+    void* stage_host = nullptr;              // page-locked host memory the stage calls' results land in before
+    size_t stage_host_cap = 0;               // they are scattered into the caller's records; grows on demand
     hipEvent_t frame_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool frame_pending = false;
@@ -613,6 +615,28 @@ extern "C" void* mrt_stage_buffer_(mrt_ctx* ctx, int slot, size_t bytes) {
     }
     return ctx->stage_buf[slot];
 }
+// Page-locked host memory of the ctx with room for `bytes` (the ctx's GPU must be current): where a
+// stage call's results arrive from the GPU -- at the link's rate, with no page of a fresh
+// allocation to fault in -- before the host scatters them into the caller's records.  The stage
+// calls block, so one buffer serves them all.  nullptr + the ctx's error on failure.
+extern "C" void* mrt_stage_host_buffer_(mrt_ctx* ctx, size_t bytes) {
+    if (!ctx) return nullptr;
+    if (bytes == 0) bytes = 1;
+    if (bytes > ctx->stage_host_cap) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
+        ctx->stage_host = nullptr;
+        ctx->stage_host_cap = 0;
+        const hipError_t e = hipHostMalloc(&ctx->stage_host, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            ctx->stage_host = nullptr;
+            fail(ctx, MRT_ERR_HIP, std::string("hipHostMalloc of the stage calls' host buffer: ") + hipGetErrorString(e));
+            return nullptr;
+        }
+        ctx->stage_host_cap = bytes;
+    }
+    return ctx->stage_host;
+}
 // The ctx's timing events (0, 1): the stage calls block, so they never overlap a timed frame.
 extern "C" void* mrt_stage_event_(mrt_ctx* ctx, int which) { return (void*)ctx->ev[which & 1]; }
 extern "C" void mrt_stage_set_kernel_ms_(mrt_ctx* ctx, double ms) { ctx->stage_kernel_ms = ms; }
@@ -727,6 +751,7 @@ void mrt_destroy(mrt_ctx* ctx) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     for (int k = 0; k < mrt_ctx::kStageSlots; ++k) if (ctx->stage_buf[k]) (void)hipFree(ctx->stage_buf[k]);
+    if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
     for (int k = 0; k < 3; ++k) if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     for (hipEvent_t e : ctx->strip_events) if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);

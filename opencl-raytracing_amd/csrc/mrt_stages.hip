@@ -23,6 +23,7 @@
 
 extern "C" int mrt_stage_set_error_(mrt_ctx* ctx, int code, const char* msg);
 extern "C" int mrt_stage_device_(const mrt_ctx* ctx);
+extern "C" void* mrt_stage_host_buffer_(mrt_ctx* ctx, size_t bytes);
 extern "C" void* mrt_stage_buffer_(mrt_ctx* ctx, int slot, size_t bytes);
 extern "C" void* mrt_ctx_stream_(const mrt_ctx* ctx);
 extern "C" void* mrt_stage_event_(mrt_ctx* ctx, int which);
@@ -553,9 +554,11 @@ int rays_common(mrt_ctx* ctx, const mrt_cl_cam* camera, const mrt_cl_float2* uv,
     STAGE_BUF(d_uv, 0, (size_t)n * 8);
     STAGE_BUF(d_rays, 1, (size_t)n * 32);
     STAGE_COPY(d_uv.p, uv, (size_t)n * 8, hipMemcpyHostToDevice);
-    // Keep the caller's padding floats (the kernels never write .s[3]).
-    STAGE_COPY(d_rays.p, rays_out, (size_t)n * 32, hipMemcpyHostToDevice);
-    std::vector<mrt_cl_ray> tmp((size_t)n);
+    // The results come back into the ctx's page-locked buffer and only the three components the
+    // kernel computes are stored into the caller's records: the padding floats keep what the
+    // caller put there, as they do in the reference (viewRay holds two cl_float3).
+    const mrt_cl_ray* tmp = static_cast<const mrt_cl_ray*>(mrt_stage_host_buffer_(ctx, (size_t)n * 32));
+    if (!tmp) return MRT_ERR_HIP;
     if (persp)
         hipLaunchKernelGGL(mrt::stage_rays_kernel<MRT_PROJ_PERSP>, grid_for(n), dim3(256), 0, stage_stream, cam_of(camera),
                            (const float2*)d_uv.p, n, focal, (float4*)d_rays.p);
@@ -563,7 +566,7 @@ int rays_common(mrt_ctx* ctx, const mrt_cl_cam* camera, const mrt_cl_float2* uv,
         hipLaunchKernelGGL(mrt::stage_rays_kernel<MRT_PROJ_ORTHO>, grid_for(n), dim3(256), 0, stage_stream, cam_of(camera),
                            (const float2*)d_uv.p, n, focal, (float4*)d_rays.p);
     STAGE_TRY(hipGetLastError());
-    STAGE_COPY(tmp.data(), d_rays.p, (size_t)n * 32, hipMemcpyDeviceToHost);
+    STAGE_COPY(const_cast<mrt_cl_ray*>(tmp), d_rays.p, (size_t)n * 32, hipMemcpyDeviceToHost);
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < 3; ++k) {
             rays_out[i].origin.s[k] = tmp[(size_t)i].origin.s[k];
@@ -606,8 +609,9 @@ int shade_common(mrt_ctx* ctx, const mrt_cl_intersect* xsects, int n, mrt_cl_rgb
     hipLaunchKernelGGL(mrt::stage_shade_kernel, grid_for(n), dim3(256), 0, stage_stream, (const uint32_t*)d_x.p, n, k,
                        (const float4*)d_l.p, (float4*)d_o.p);
     STAGE_TRY(hipGetLastError());
-    std::vector<float4> res((size_t)n);
-    STAGE_COPY(res.data(), d_o.p, (size_t)n * 16, hipMemcpyDeviceToHost);
+    float4* res = static_cast<float4*>(mrt_stage_host_buffer_(ctx, (size_t)n * 16));
+    if (!res) return MRT_ERR_HIP;
+    STAGE_COPY(res, d_o.p, (size_t)n * 16, hipMemcpyDeviceToHost);
     for (int i = 0; i < n; ++i) {
         out[i].r = res[(size_t)i].x; out[i].g = res[(size_t)i].y; out[i].b = res[(size_t)i].z;
         // flat_shader never writes .a (kernel.cl:381-396); phong_shader copies
@@ -765,8 +769,9 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
                        (mrt::HitOut*)d_out.p);
     STAGE_TRY(hipGetLastError());
     STAGE_TRY(hipEventRecord(ev1, stage_stream));
-    std::vector<mrt::HitOut> res((size_t)n_rays);
-    STAGE_COPY(res.data(), d_out.p, (size_t)n_rays * sizeof(mrt::HitOut), hipMemcpyDeviceToHost);
+    const mrt::HitOut* res = static_cast<const mrt::HitOut*>(mrt_stage_host_buffer_(ctx, (size_t)n_rays * sizeof(mrt::HitOut)));
+    if (!res) return MRT_ERR_HIP;
+    STAGE_COPY(const_cast<mrt::HitOut*>(res), d_out.p, (size_t)n_rays * sizeof(mrt::HitOut), hipMemcpyDeviceToHost);
     float kernel_ms = 0.f;
     STAGE_TRY(hipEventElapsedTime(&kernel_ms, ev0, ev1));
     mrt_stage_set_kernel_ms_(ctx, (double)kernel_ms);
