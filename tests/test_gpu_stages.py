@@ -115,6 +115,27 @@ def test_stage_pipeline_matches_oracle(gpu_ctx, mrt, oracle, name, n_side):
     assert np.array_equal(ph_g["a"], ph_o["a"])     # background.a on a miss, untouched on a hit
 
 
+def test_stage_viewrays_keep_the_padding_floats(gpu_ctx, mrt, oracle):
+    """viewRay holds two cl_float3 (CLStructs.hpp): the kernels assign three components of each
+    (kernel.cl:130-147), so the fourth float of origin and direction keeps what the caller's array
+    held -- in the library, which does not upload that array, as in the oracle."""
+    for name in ("scene_2spheres_persp_flat", "scene_2spheres_ortho_flat"):
+        sc = scene_py.load_scene(SCENES / f"{name}.json")
+        pos, vp, cam, _, _, _ = make_inputs(mrt, sc, 48)
+        uv = gpu_ctx.stage_uv(pos, vp)
+        focal = None if sc.struct.projection == mrt.PROJ_ORTHO else sc.struct.focal
+        pre = np.zeros(len(uv), mrt.CL_DTYPES["ray"])
+        raw = pre.view(np.uint8).reshape(len(pre), 32)
+        raw[:, 12:16] = 0xC3
+        raw[:, 28:32] = 0x3C
+        g = gpu_ctx.stage_viewrays(cam, uv, focal, out=pre.view(np.uint8).copy().view(pre.dtype))
+        o = oracle.stage_viewrays(cam, uv, focal, out=pre.view(np.uint8).copy().view(pre.dtype))
+        graw, oraw = (a.view(np.uint8).reshape(len(a), 32) for a in (g, o))
+        assert np.array_equal(graw, oraw)
+        assert (graw[:, 12:16] == 0xC3).all() and (graw[:, 28:32] == 0x3C).all()
+        assert graw[:, 16:28].any()                                     # ... and the directions were written
+
+
 def test_stage_intersect_bounds_and_untouched_bytes(gpu_ctx, mrt, oracle):
     """t range is (lower, upper) for the loop, a miss writes three fields only."""
     sc = scene_py.load_scene(SCENES / "scene_2spheres_persp_flat.json")
