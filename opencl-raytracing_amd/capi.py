@@ -221,6 +221,8 @@ def lib():
     L.mrt_synchronize.argtypes = [vp]
     L.mrt_set_slices_override_.argtypes = [vp, C.c_uint32]
     L.mrt_set_slices_override_.restype = None
+    L.mrt_stage_last_t_switches_.argtypes = [vp]
+    L.mrt_stage_last_t_switches_.restype = C.c_uint32
     L.mrt_render_rgba8.argtypes = [vp, vp, C.POINTER(Stats)]
     L.mrt_render_debug.argtypes = [vp, vp, vp, vp, C.POINTER(Stats)]
     L.mrt_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
@@ -507,6 +509,11 @@ class Context:
                                               len(objects), rays.ctypes.data, len(rays), float(t_upper),
                                               float(t_lower), xs.ctypes.data))
         return xs
+
+    def stage_t_switches(self):
+        """Tuning / test aid (not part of the public ABI): waves of the last stage_intersect call that took
+        up the filter with the fourth determinant."""
+        return int(lib().mrt_stage_last_t_switches_(self._h))
 
     def stage_kernel_ms(self):
         """Device time of the kernels of the last stage_intersect call (HIP events)."""

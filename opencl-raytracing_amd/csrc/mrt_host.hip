@@ -139,6 +139,7 @@ struct mrt_ctx {
     void* stage_buf[kStageSlots] = {};
     size_t stage_cap[kStageSlots] = {};
     double stage_kernel_ms = 0.0;            // device time of the kernels of the last mrt_stage_intersect
+    uint32_t stage_t_switches = 0;           // ... and how many of its waves took up the fourth determinant
     void* stage_host = nullptr;              // page-locked host memory the stage calls' results land in before
     size_t stage_host_cap = 0;               // they are scattered into the caller's records; grows on demand
     hipEvent_t frame_done = nullptr;
@@ -641,6 +642,10 @@ extern "C" void* mrt_stage_host_buffer_(mrt_ctx* ctx, size_t bytes) {
 extern "C" void* mrt_stage_event_(mrt_ctx* ctx, int which) { return (void*)ctx->ev[which & 1]; }
 extern "C" void mrt_stage_set_kernel_ms_(mrt_ctx* ctx, double ms) { ctx->stage_kernel_ms = ms; }
 extern "C" double mrt_stage_get_kernel_ms_(const mrt_ctx* ctx) { return ctx->stage_kernel_ms; }
+// Tests and tuning scripts: waves of the last mrt_stage_intersect that switched to the filter with
+// the fourth determinant.  Not part of the public ABI.
+extern "C" void mrt_stage_set_t_switches_(mrt_ctx* ctx, uint32_t n) { ctx->stage_t_switches = n; }
+extern "C" uint32_t mrt_stage_last_t_switches_(const mrt_ctx* ctx) { return ctx ? ctx->stage_t_switches : 0u; }
 // Tests and tuning scripts: cut the primitive list of this ctx's frames into n slices / layers
 // (clamped to what the frame allows), 0 = the automatic choice.  Not part of the public ABI.
 extern "C" void mrt_set_slices_override_(mrt_ctx* ctx, uint32_t n) { if (ctx) ctx->force_slices = n > 65536u ? 65536u : n; }

@@ -14,6 +14,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -24,6 +26,7 @@
 extern "C" int mrt_stage_set_error_(mrt_ctx* ctx, int code, const char* msg);
 extern "C" int mrt_stage_device_(const mrt_ctx* ctx);
 extern "C" void* mrt_stage_host_buffer_(mrt_ctx* ctx, size_t bytes);
+extern "C" void mrt_stage_set_t_switches_(mrt_ctx* ctx, uint32_t n);
 extern "C" void* mrt_stage_buffer_(mrt_ctx* ctx, int slot, size_t bytes);
 extern "C" void* mrt_ctx_stream_(const mrt_ctx* ctx);
 extern "C" void* mrt_stage_event_(mrt_ctx* ctx, int which);
@@ -134,8 +137,10 @@ __device__ __forceinline__ bool is_wild(float4 ro, float4 rd) {
 // four rays per thread, one set of atomics per block.  Also sets every ray's key to "no hit".
 __global__ __launch_bounds__(256) void general_ray_bounds(const float4* __restrict__ rays, int n_rays,
                                                           uint32_t* __restrict__ bounds,
-                                                          unsigned long long* __restrict__ keys) {
+                                                          unsigned long long* __restrict__ keys,
+                                                          uint32_t* __restrict__ t_switches) {
     __shared__ float s_m[4][6];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *t_switches = 0u;      // counted by general_intersect_kernel
     float m[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rays; i += gridDim.x * blockDim.x) {
         const float4 ro = rays[2 * (size_t)i], rd = rays[2 * (size_t)i + 1];
@@ -239,18 +244,29 @@ __global__ void prep_general_records(const float4* __restrict__ geo, const uint3
     rec[(size_t)k * kGenRecFloat4 + 4] = r4;
 }
 
-// HAS_T: t_lower >= 0, so an accepted t is positive and Nt takes part in the sign test.
-//
 // The pairs the filter cannot rule out are rare and scattered over lanes and rays, so they are
 // not tested where they are found: the wave appends (ray, object) to a queue of its own in LDS
 // and, whenever 64 are waiting (and once more at the end), every lane takes one entry, reads its
 // ray and its object from memory and runs the reference arithmetic -- all 64 lanes busy, nothing
 // held in registers while the filter loop runs.
-template <bool HAS_T>
+//
+// The fourth determinant.  When t_lower >= 0 an accepted t is positive, so Nt must have the sign
+// of det as well.  That test costs three fused multiply-adds and two verdict instructions per
+// pair and rules out only pairs whose LINE meets the triangle behind the ray's origin -- as rare
+// as the hits themselves in most scenes, and then cheaper to leave to the reference arithmetic:
+// 160 000 x 4034 without it 0.28-0.29 ms against 0.33-0.35 with it, for the camera's primary rays
+// and for rays that start inside the mesh alike.  A wave therefore starts without it and takes it
+// up (t_filter_allowed: t_lower >= 0) only when the pairs it has passed on so far outnumber
+// kSwitchRate per triangle of its 512 rays -- large overlapping triangles behind the rays, where
+// the cheaper filter would pass every pair on.  Either filter only ever rejects what the
+// reference arithmetic rejects, so the records do not depend on the choice.
+constexpr uint32_t kSwitchRate = 10, kSwitchGrace = 8;
+
 __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
     const float4* __restrict__ rays, int n_rays, const float4* __restrict__ tri_rec, int n_tri, int tris_per_slice,
     const float4* __restrict__ sph_rec, int n_sph, int sph_per_slice, const float4* __restrict__ geo,
-    float t_upper, float t_lower, unsigned long long* __restrict__ keys) {
+    float t_upper, float t_lower, int t_filter_allowed, unsigned long long* __restrict__ keys,
+    uint32_t* __restrict__ t_switches) {
     __shared__ float4 s_rec[kGenChunk * kGenRecFloat4];
     __shared__ uint2 s_queue[kGenThreads / 64][kGenQueue];
     const int tid = threadIdx.x;
@@ -277,6 +293,8 @@ __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
     }
     const uint32_t wild_sign = wild ? 0x80000000u : 0u;
     uint32_t queued = 0;                                  // entries waiting in the wave's queue (wave-uniform)
+    uint32_t passed_on = 0;                               // pairs this wave has handed to the reference arithmetic (wave-uniform)
+    bool use_t = false;                                   // the fourth determinant takes part in the filter (wave-uniform)
 
     // The reference arithmetic for `count` queue entries from `from` on, one per lane.
     auto run_queue = [&](uint32_t from, uint32_t count) {
@@ -311,6 +329,7 @@ __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
             queue[queued + before] = make_uint2(i, obj);
         }
         queued += (uint32_t)__builtin_popcountll(mask);
+        passed_on += (uint32_t)__builtin_popcountll(mask);
     };
     auto drain = [&](uint32_t keep) {
         while (queued > keep) {
@@ -332,45 +351,62 @@ __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
             if (i < count * kGenRecFloat4) s_rec[i] = tri_rec[(size_t)cbase * kGenRecFloat4 + i];
         }
         __syncthreads();
-        for (int g = 0; g < count; ++g) {
-            const float4 q0 = s_rec[g * kGenRecFloat4 + 0];
-            const float4 q1 = s_rec[g * kGenRecFloat4 + 1];
-            const float4 q2 = s_rec[g * kGenRecFloat4 + 2];
-            const float4 q3 = s_rec[g * kGenRecFloat4 + 3];
-            const float4 q4 = s_rec[g * kGenRecFloat4 + 4];
-            const F3 a2 = mk3(q0.x, q0.y, q0.z), na1 = mk3(q1.x, q1.y, q1.z), ns2 = mk3(q2.x, q2.y, q2.z);
-            const F3 s1 = mk3(q3.x, q3.y, q3.z), n = mk3(q4.x, q4.y, q4.z);
-            // The sign bit of c[s] is set when ray s may hit: all X >= 0 (a hit with det > 0) or
-            // all X <= 2M (det < 0).
-            uint32_t c[kGenRays];
-            uint32_t any = wild_sign;
+        // Two loops over the chunk's triangles, one per filter, each compiled on its own (one loop
+        // with a branch per triangle around the two bodies spills 52 registers into its survivor
+        // path and is slower than either): the wave runs the cheaper one until the rate of pairs
+        // passed on says otherwise, then the other from that triangle on, in this chunk and the next.
+        auto scan = [&](auto with_t_tag, int g_begin) -> int {
+            constexpr bool WITH_T = decltype(with_t_tag)::value;
+            for (int g = g_begin; g < count; ++g) {
+                const float4 q0 = s_rec[g * kGenRecFloat4 + 0];
+                const float4 q1 = s_rec[g * kGenRecFloat4 + 1];
+                const float4 q2 = s_rec[g * kGenRecFloat4 + 2];
+                const float4 q3 = s_rec[g * kGenRecFloat4 + 3];
+                const float4 q4 = s_rec[g * kGenRecFloat4 + 4];
+                const F3 a2 = mk3(q0.x, q0.y, q0.z), na1 = mk3(q1.x, q1.y, q1.z), ns2 = mk3(q2.x, q2.y, q2.z);
+                const F3 s1 = mk3(q3.x, q3.y, q3.z), n = mk3(q4.x, q4.y, q4.z);
+                // The sign bit of c[s] is set when ray s may hit: all X >= 0 (a hit with det > 0) or
+                // all X <= 2M (det < 0).
+                uint32_t c[kGenRays];
+                uint32_t any = wild_sign;
 #pragma unroll
-            for (int s = 0; s < kGenRays; ++s) {
-                const float xb = dot_fma(ns2, rm[s], dot_fma(a2, rd[s], q0.w));
-                const float xg = dot_fma(s1, rm[s], dot_fma(na1, rd[s], q0.w));
-                const float xd = dot_fma(n, rd[s], q1.w);
-                const float xw = (xd - xb) - xg;
-                float nlo = __builtin_fmaxf(__builtin_fmaxf(-xb, -xg), -xw);
-                float hi = __builtin_fmaxf(__builtin_fmaxf(xb, xg), xw);
-                if (HAS_T) {
-                    const float xt = dot_fma(n, rno[s], q4.w);
-                    nlo = __builtin_fmaxf(nlo, -xt);
-                    hi = __builtin_fmaxf(hi, xt);
+                for (int s = 0; s < kGenRays; ++s) {
+                    const float xb = dot_fma(ns2, rm[s], dot_fma(a2, rd[s], q0.w));
+                    const float xg = dot_fma(s1, rm[s], dot_fma(na1, rd[s], q0.w));
+                    const float xd = dot_fma(n, rd[s], q1.w);
+                    const float xw = (xd - xb) - xg;
+                    float nlo = __builtin_fmaxf(__builtin_fmaxf(-xb, -xg), -xw);
+                    float hi = __builtin_fmaxf(__builtin_fmaxf(xb, xg), xw);
+                    if (WITH_T) {
+                        const float xt = dot_fma(n, rno[s], q4.w);
+                        nlo = __builtin_fmaxf(nlo, -xt);
+                        hi = __builtin_fmaxf(hi, xt);
+                    }
+                    c[s] = __float_as_uint(nlo) | __float_as_uint(hi - q2.w);
+                    any |= c[s];
                 }
-                c[s] = __float_as_uint(nlo) | __float_as_uint(hi - q2.w);
-                any |= c[s];
-            }
-            // (the compare's lane mask itself is the vote: no round trip through a VGPR)
-            if (__builtin_amdgcn_sicmp((int32_t)any, 0, 40 /* ICMP_SLT */) == 0) continue;
-            const uint32_t obj = __builtin_amdgcn_readfirstlane(__float_as_uint(q3.w));
+                // (the compare's lane mask itself is the vote: no round trip through a VGPR)
+                if (__builtin_amdgcn_sicmp((int32_t)any, 0, 40 /* ICMP_SLT */) == 0) continue;
+                const uint32_t obj = __builtin_amdgcn_readfirstlane(__float_as_uint(q3.w));
 #pragma unroll
-            for (int s = 0; s < kGenRays; ++s) {
-                const bool mine = (int32_t)(c[s] | ((wild >> s) << 31)) < 0;
-                const uint64_t mask = __builtin_amdgcn_ballot_w64(mine);
-                if (mask) push(mask, mine, s, obj);
+                for (int s = 0; s < kGenRays; ++s) {
+                    const bool mine = (int32_t)(c[s] | ((wild >> s) << 31)) < 0;
+                    const uint64_t mask = __builtin_amdgcn_ballot_w64(mine);
+                    if (mask) push(mask, mine, s, obj);
+                }
+                drain(63u);
+                // too many pairs passed on for the triangles seen so far: the fourth determinant from here on
+                if (!WITH_T && t_filter_allowed && passed_on > kSwitchRate * ((uint32_t)(cbase - t_begin + g) + kSwitchGrace)) {
+                    use_t = true;
+                    if (lane == 0) atomicAdd(t_switches, 1u);           // (a diagnostic: once per wave at most)
+                    return g + 1;
+                }
             }
-            drain(63u);
-        }
+            return count;
+        };
+        int g_next = 0;
+        if (!use_t) g_next = scan(std::false_type{}, 0);
+        if (g_next < count) (void)scan(std::true_type{}, g_next);
     }
 
     // ---- spheres of this slice ----
@@ -706,7 +742,10 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
     DevBuf d_pack, d_rays, d_out, d_rec, d_keys;
     STAGE_BUF(d_pack, 0, pack_bytes);
     STAGE_BUF(d_rays, 1, (size_t)n_rays * 32);
-    STAGE_BUF(d_out, 2, (size_t)n_rays * sizeof(mrt::HitOut));
+    // (the hit records, and behind them the word that counts the waves which took up the fourth determinant)
+    const size_t out_bytes = (size_t)n_rays * sizeof(mrt::HitOut);
+    STAGE_BUF(d_out, 2, out_bytes + sizeof(mrt::HitOut));
+    uint32_t* d_switches = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(d_out.p) + out_bytes);
     STAGE_BUF(d_rec, 3, (size_t)(n_tri ? n_tri : 1) * mrt::kGenRecFloat4 * sizeof(float4));
     STAGE_BUF(d_keys, 4, (size_t)n_rays * sizeof(unsigned long long));
     unsigned char* dp = static_cast<unsigned char*>(d_pack.p);
@@ -744,7 +783,7 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
     {
         const int blocks = (n_rays + 1023) / 1024;
         hipLaunchKernelGGL(mrt::general_ray_bounds, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, stage_stream,
-                           (const float4*)d_rays.p, n_rays, d_bounds, (unsigned long long*)d_keys.p);
+                           (const float4*)d_rays.p, n_rays, d_bounds, (unsigned long long*)d_keys.p, d_switches);
         STAGE_TRY(hipGetLastError());
     }
     if (n_tri) {
@@ -754,14 +793,15 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
     }
     if (n_objects) {
         const dim3 grid((unsigned)ray_blocks, 1, (unsigned)slices);
-        if (t_lower_bound >= 0.0f)
-            hipLaunchKernelGGL(mrt::general_intersect_kernel<true>, grid, dim3(mrt::kGenThreads), 0, stage_stream,
-                               (const float4*)d_rays.p, n_rays, (const float4*)d_rec.p, n_tri, tris_per_slice, d_sph, n_sph,
-                               sph_per_slice, d_geo, t_upper_bound, t_lower_bound, (unsigned long long*)d_keys.p);
-        else
-            hipLaunchKernelGGL(mrt::general_intersect_kernel<false>, grid, dim3(mrt::kGenThreads), 0, stage_stream,
-                               (const float4*)d_rays.p, n_rays, (const float4*)d_rec.p, n_tri, tris_per_slice, d_sph, n_sph,
-                               sph_per_slice, d_geo, t_upper_bound, t_lower_bound, (unsigned long long*)d_keys.p);
+        // (tuning aid, read once per process: MRT_STAGE_T_FILTER=0 never lets a wave take up the fourth determinant)
+        static const int t_filter = [] {
+            const char* e = std::getenv("MRT_STAGE_T_FILTER");
+            return e ? (int)std::strtol(e, nullptr, 10) : 1;
+        }();
+        hipLaunchKernelGGL(mrt::general_intersect_kernel, grid, dim3(mrt::kGenThreads), 0, stage_stream,
+                           (const float4*)d_rays.p, n_rays, (const float4*)d_rec.p, n_tri, tris_per_slice, d_sph, n_sph,
+                           sph_per_slice, d_geo, t_upper_bound, t_lower_bound, (t_lower_bound >= 0.0f && t_filter) ? 1 : 0,
+                           (unsigned long long*)d_keys.p, d_switches);
         STAGE_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(mrt::general_finish_kernel, grid_for(n_rays), dim3(256), 0, stage_stream, d_geo,
@@ -769,9 +809,14 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
                        (mrt::HitOut*)d_out.p);
     STAGE_TRY(hipGetLastError());
     STAGE_TRY(hipEventRecord(ev1, stage_stream));
-    const mrt::HitOut* res = static_cast<const mrt::HitOut*>(mrt_stage_host_buffer_(ctx, (size_t)n_rays * sizeof(mrt::HitOut)));
+    const mrt::HitOut* res = static_cast<const mrt::HitOut*>(mrt_stage_host_buffer_(ctx, out_bytes + sizeof(mrt::HitOut)));
     if (!res) return MRT_ERR_HIP;
-    STAGE_COPY(const_cast<mrt::HitOut*>(res), d_out.p, (size_t)n_rays * sizeof(mrt::HitOut), hipMemcpyDeviceToHost);
+    STAGE_COPY(const_cast<mrt::HitOut*>(res), d_out.p, out_bytes + sizeof(mrt::HitOut), hipMemcpyDeviceToHost);
+    {
+        uint32_t switched = 0;
+        std::memcpy(&switched, res + n_rays, sizeof switched);
+        mrt_stage_set_t_switches_(ctx, switched);
+    }
     float kernel_ms = 0.f;
     STAGE_TRY(hipEventElapsedTime(&kernel_ms, ev0, ev1));
     mrt_stage_set_kernel_ms_(ctx, (double)kernel_ms);

@@ -255,6 +255,63 @@ def test_stage_intersect_arbitrary_rays(gpu_ctx, mrt, oracle, seed, n_tri, n_sph
     assert gpu_ctx.stage_kernel_ms() > 0.0
 
 
+def stacked_sheets(mrt, n_tri, z_lo=1.0, z_hi=4.0):
+    """n_tri large triangles, one above the other, each covering the square |x|, |y| <= 2: every
+    line through that square parallel to z meets every one of them."""
+    objs = np.zeros(n_tri, mrt.CL_DTYPES["object"])
+    z = np.linspace(z_lo, z_hi, n_tri).astype(np.float32)
+    objs["a"][:, :3] = np.stack([np.full(n_tri, -9.0), np.full(n_tri, -6.0), z], axis=1)
+    objs["b"][:, :3] = np.stack([np.full(n_tri, 9.0), np.full(n_tri, -6.0), z], axis=1)
+    objs["c"][:, :3] = np.stack([np.full(n_tri, 0.0), np.full(n_tri, 12.0), z], axis=1)
+    objs["tri_color"][:, :3] = 0.5
+    objs["tri_shininess"][:] = 8.0
+    objs["is_triangle"][:] = 1
+    return objs
+
+
+def test_stage_intersect_takes_up_the_fourth_determinant(gpu_ctx, mrt, oracle):
+    """The kernel's filter starts without the determinant that carries the sign of t and takes it
+    up, wave by wave, only where lines meet many triangles behind their rays.  Rays above a stack
+    of sheets that look away from it (every sheet behind every ray: the waves must switch), rays
+    that look at it (every sheet a hit: nothing to gain, no harm), both mixed, and the camera's
+    primary rays on the teatime mesh (no wave switches): the records are the oracle's whichever
+    filter ran, for t ranges on either side of zero."""
+    rng = np.random.default_rng(11)
+    objs = stacked_sheets(mrt, 600)
+    n = 6000
+    FLT_MAX = float(np.finfo(np.float32).max)
+
+    def rays_from_above(sign):
+        rays = np.zeros(n, mrt.CL_DTYPES["ray"])
+        rays["origin"][:, 0:2] = rng.uniform(-2, 2, (n, 2))
+        rays["origin"][:, 2] = 5.0
+        rays["direction"][:, 0:2] = rng.uniform(-0.01, 0.01, (n, 2))
+        rays["direction"][:, 2] = sign if np.isscalar(sign) else sign
+        return rays
+
+    away, toward = rays_from_above(1.0), rays_from_above(-1.0)
+    mixed = rays_from_above(np.where(rng.random(n) < 0.5, 1.0, -1.0).astype(np.float32))
+    for name, rays, must_switch in (("away", away, True), ("toward", toward, None), ("mixed", mixed, None)):
+        for hi, lo in [(FLT_MAX, 0.0), (2.0, 0.5), (FLT_MAX, -10.0)]:
+            g = gpu_ctx.stage_intersect(objs, rays, hi, lo)
+            switched = gpu_ctx.stage_t_switches()
+            o, ids = oracle.stage_intersect(objs, rays, hi, lo)
+            same_records(g, o)
+            if lo < 0:
+                assert switched == 0, (name, hi, lo)          # t may be negative: the determinant says nothing
+                assert (ids >= 0).all()
+            elif must_switch:
+                assert switched > 0, (name, hi, lo)
+                assert (ids < 0).all()
+    sc = scene_py.load_scene(SCENES / "teatime.json")
+    pos, vp, cam, tobjs, _, _ = make_inputs(mrt, sc, 128)
+    prim = gpu_ctx.stage_viewrays(cam, gpu_ctx.stage_uv(pos, vp), sc.struct.focal)
+    g = gpu_ctx.stage_intersect(tobjs, prim, FLT_MAX, 0.0)
+    assert gpu_ctx.stage_t_switches() == 0
+    o, ids = oracle_intersect_threads(oracle, tobjs, prim, FLT_MAX, 0.0)
+    same_records(g, o)
+
+
 def test_stage_intersect_wild_rays_and_odd_objects(gpu_ctx, mrt, oracle):
     """Non-finite and huge ray components, rays of zero direction, degenerate and enormous
     triangles, spheres of zero / negative / NaN radius: whatever the reference arithmetic makes of
