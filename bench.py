@@ -63,8 +63,9 @@ FLOPS_PER_SPH_TEST = 20.0
 # what the kernels execute per (ray, triangle) pair, a fused multiply-add counted as two:
 # full_trace_kernel: two cross products (6 mul + 6 fma) + three dot products (9 fma) + 1 sub
 FULL_TRACE_EXECUTED_FLOPS = 37.0
-# general_intersect_kernel: six dot products (18 fma) + 2 sub
-GENERAL_RAY_EXECUTED_FLOPS = 38.0
+# general_intersect_kernel on this workload: five dot products (15 fma) + 2 sub -- the sixth, the
+# determinant that carries the sign of t, joins a wave's filter only where it pays (not here)
+GENERAL_RAY_EXECUTED_FLOPS = 32.0
 FP32_PEAK_TFLOPS = 157.3          # 256 CU x 128 lanes x 2 FLOP x 2.4 GHz
 VALU_ISSUE_PEAK = 78.6e12         # lane-ops/s: 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
 BAND_ROWS = 64
@@ -475,9 +476,10 @@ def general_ray(env, reps=12):
             "frac_executed": achieved / FP32_PEAK_TFLOPS * GENERAL_RAY_EXECUTED_FLOPS / FLOPS_PER_TRI_TEST,
             "teatime_4k_rays": big,
             "note": "arbitrary rays: origin and direction per ray from memory, caller's t range, objects in any order; "
-                    "per pair six dot products of the ray's (direction, moment, origin) with per-triangle vectors (the "
-                    "four determinants of tri_intersect's Cramer solve) as a conservative filter, the reference's unfused "
-                    "arithmetic for the survivors; bit-identical records to the oracle's per-ray loop"}
+                    "per pair five dot products of the ray's (direction, moment) with per-triangle vectors (three of the "
+                    "four determinants of tri_intersect's Cramer solve; the fourth, which carries the sign of t, joins a "
+                    "wave's filter only where lines meet many triangles behind their rays) as a conservative filter, the "
+                    "reference's unfused arithmetic for the survivors; bit-identical records to the oracle's per-ray loop"}
 
 
 def host_side_handshake(env, key):

@@ -86,7 +86,8 @@ __global__ void stage_rays_kernel(CamK c, const float2* __restrict__ uv, int n, 
 //     det = d . n     Nt = k - o . n     Nb = d . A2 - s2 . m     Ng = s1 . m - d . A1
 // -- the four determinants of a general ray as six dot products of the
 // ray's (d, m, o) with per-triangle vectors, 18 fused multiply-adds per pair
-// and neither a subtraction nor a cross product.  It is a conservative filter,
+// and neither a subtraction nor a cross product (15 without Nt, which a wave
+// leaves out until it pays: see the kernel).  It is a conservative filter,
 // never the decision: a hit needs Nb, Ng and W = det - Nb - Ng (and Nt, when t_lower >= 0)
 // to have the sign of det, and since det = Nb + Ng + W that is "all of one
 // sign".  The fused values differ from the reference's unfused ones by less than
