@@ -593,12 +593,15 @@ int mrt_stage_persp_viewrays(mrt_ctx *ctx, const mrt_cl_cam *camera, const mrt_c
  * go through registers eight to a lane, objects through LDS in chunks, and the
  * object list is cut into slices (grid layers) that meet in one 64-bit (t, index)
  * key per ray, so that the reference's own 160000 rays fill the GPU.  Per
- * (ray, triangle) pair the kernel forms a - origin, one cross product and the
- * four determinants of tri_intersect's Cramer solve (kernel.cl:187-213) with
- * fused multiply-adds, as a conservative filter; the pairs it cannot rule out
- * (about one in two thousand on the shipped mesh) and every pair of a ray with
- * non-finite or huge components run the reference's own unfused arithmetic,
- * which decides.  Bit-identical records to the per-ray loop of the reference. */
+ * (ray, triangle) pair the kernel forms the determinants of tri_intersect's
+ * Cramer solve (kernel.cl:187-213) as dot products of the ray's direction and
+ * moment (direction x origin) with per-triangle vectors, in fused
+ * multiply-adds -- det, N_beta, N_gamma always; N_t, which carries the sign of
+ * t, only in waves whose rays have much geometry behind them -- as a
+ * conservative filter; the pairs it cannot rule out (about one in two thousand
+ * on the shipped mesh) and every pair of a ray with non-finite or huge
+ * components run the reference's own unfused arithmetic, which decides.
+ * Bit-identical records to the per-ray loop of the reference. */
 int mrt_stage_intersect(mrt_ctx *ctx, const mrt_cl_object *objects, int n_objects,
                         const mrt_cl_ray *rays, int n_rays, float t_upper_bound,
                         float t_lower_bound, mrt_cl_intersect *out);
