@@ -388,6 +388,10 @@ __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
                 }
                 // (the compare's lane mask itself is the vote: no round trip through a VGPR)
                 if (__builtin_amdgcn_sicmp((int32_t)any, 0, 40 /* ICMP_SLT */) == 0) continue;
+#ifdef MRT_GEN_NO_SURVIVORS
+                // timing-only build (wrong records): what the survivors' path costs
+                if (any != 0x12345678u) continue;
+#endif
                 const uint32_t obj = __builtin_amdgcn_readfirstlane(__float_as_uint(q3.w));
 #pragma unroll
                 for (int s = 0; s < kGenRays; ++s) {
