@@ -609,7 +609,18 @@ def main():
     elapsed_one = job1.timed(args.steps, args.warmup)
     job1.close()
     trace_avg, shade_avg = job.kernel_ms(max(10, min(args.steps, 50)))
-    host = host_frame(env, job, st.xres * st.yres) if (world == 1 and rank == 0) else None
+    # Everything beyond the contract's keys is reported when it works and named when it does not:
+    # a failure in an extra must not cost the run its JSON line.
+    extras_failed = {}
+
+    def attempt(name, fn, *a, **kw):
+        try:
+            return fn(*a, **kw)
+        except Exception as e:                      # noqa: BLE001
+            extras_failed[name] = repr(e)[:300]
+            return None
+
+    host = attempt("host_frame", host_frame, env, job, st.xres * st.yres) if (world == 1 and rank == 0) else None
     job.close()
 
     # The same frame (this rank's rows of it) with MRT_FLAG_FULL_TEST: no rejection in screen space,
@@ -687,17 +698,21 @@ def main():
                             "not by algorithmic FLOPs",
         }
         if world == 1:
-            out["general_ray"] = general_ray(env)
+            g = attempt("general_ray", general_ray, env)
+            if g is not None:
+                out["general_ray"] = g
         if host is not None:
             out["host_frame"] = host
-            cam_t = set_camera_cost(env, sc)
-            cam_s = set_camera_cost(env, mrt.LoadedScene(text=mkscene.soup(1024, 1024)).copy())
-            out["set_camera_ms_teatime"] = cam_t["with_device_work_ms"]
-            out["set_camera_ms_soup"] = cam_s["with_device_work_ms"]
-            out["set_camera"] = {"teatime_4k": cam_t, "soup_17408_primitives": cam_s}
+            cam_t = attempt("set_camera_teatime", set_camera_cost, env, sc)
+            cam_s = attempt("set_camera_soup", set_camera_cost, env, mrt.LoadedScene(text=mkscene.soup(1024, 1024)).copy())
+            if cam_t is not None and cam_s is not None:
+                out["set_camera_ms_teatime"] = cam_t["with_device_work_ms"]
+                out["set_camera_ms_soup"] = cam_s["with_device_work_ms"]
+                out["set_camera"] = {"teatime_4k": cam_t, "soup_17408_primitives": cam_s}
     if not args.no_secondary:
-        sec = secondary_workloads(env, mkscene)
-        if rank == 0:
+        # (every rank takes part; a failure that is the same on every rank leaves them in step)
+        sec = attempt("secondary", secondary_workloads, env, mkscene)
+        if rank == 0 and sec is not None:
             out["secondary"] = sec
             # strong scaling of one fixed frame over the N ranks, as flat keys
             if "soup16k_full_test_every_pair" in sec:
@@ -737,9 +752,13 @@ def main():
             host_side_handshake(env, "native_multi_gpu_done")
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sc)
-            out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-            out["full_test_vs_cpu_baseline"] = out["full_test_mrays_per_s"] / out["cpu_baseline"]["value"]
+            cb = attempt("cpu_baseline", cpu_baseline, sc)
+            if cb is not None:
+                out["cpu_baseline"] = cb
+                out["vs_cpu_baseline"] = value / cb["value"]
+                out["full_test_vs_cpu_baseline"] = out["full_test_mrays_per_s"] / cb["value"]
+        if extras_failed:
+            out["extras_failed"] = extras_failed
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
