@@ -263,6 +263,14 @@ __global__ void prep_general_records(const float4* __restrict__ geo, const uint3
 // reference arithmetic rejects, so the records do not depend on the choice.
 constexpr uint32_t kSwitchRate = 10, kSwitchGrace = 8;
 
+// Measurement aid: -DMRT_GEN_SERIAL_CHAINS keeps the instruction scheduler from interleaving a
+// ray's dot-product chains (every instruction then depends on the one before it).
+#ifdef MRT_GEN_SERIAL_CHAINS
+#define MRT_GEN_CHAIN_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define MRT_GEN_CHAIN_FENCE do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
     const float4* __restrict__ rays, int n_rays, const float4* __restrict__ tri_rec, int n_tri, int tris_per_slice,
     const float4* __restrict__ sph_rec, int n_sph, int sph_per_slice, const float4* __restrict__ geo,
@@ -373,8 +381,11 @@ __global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
 #pragma unroll
                 for (int s = 0; s < kGenRays; ++s) {
                     const float xb = dot_fma(ns2, rm[s], dot_fma(a2, rd[s], q0.w));
+                    MRT_GEN_CHAIN_FENCE;
                     const float xg = dot_fma(s1, rm[s], dot_fma(na1, rd[s], q0.w));
+                    MRT_GEN_CHAIN_FENCE;
                     const float xd = dot_fma(n, rd[s], q1.w);
+                    MRT_GEN_CHAIN_FENCE;
                     const float xw = (xd - xb) - xg;
                     float nlo = __builtin_fmaxf(__builtin_fmaxf(-xb, -xg), -xw);
                     float hi = __builtin_fmaxf(__builtin_fmaxf(xb, xg), xw);
