@@ -113,7 +113,10 @@ struct HitOut { float4 loc_t; float4 n_id; };
 constexpr int kGenRays = 8;              // rays per lane
 constexpr int kGenThreads = 256;
 constexpr int kGenBlockRays = kGenThreads * kGenRays;
-constexpr int kGenChunk = 256;           // triangle records per LDS chunk (5 float4 each: 20 KiB)
+#ifndef MRT_GEN_CHUNK
+#define MRT_GEN_CHUNK 256
+#endif
+constexpr int kGenChunk = MRT_GEN_CHUNK; // triangle records per LDS chunk (5 float4 each: 20 KiB)
 constexpr int kGenRecFloat4 = 5;
 constexpr int kGenSphFloat4 = 2;         // (cx, cy, cz, r) (object index, -, -, -)
 constexpr int kGenQueue = 64 + kGenRays * 64;   // (ray, object) pairs awaiting the reference arithmetic, per wave
