@@ -110,7 +110,13 @@ __global__ void stage_rays_kernel(CamK c, const float2* __restrict__ uv, int n, 
 // ---------------------------------------------------------------------------
 struct HitOut { float4 loc_t; float4 n_id; };
 
-constexpr int kGenRays = 8;              // rays per lane
+#ifndef MRT_GEN_RAYS
+#define MRT_GEN_RAYS 8
+#endif
+#ifndef MRT_GEN_WAVES
+#define MRT_GEN_WAVES 4
+#endif
+constexpr int kGenRays = MRT_GEN_RAYS;   // rays per lane
 constexpr int kGenThreads = 256;
 constexpr int kGenBlockRays = kGenThreads * kGenRays;
 #ifndef MRT_GEN_CHUNK
@@ -274,7 +280,7 @@ constexpr uint32_t kSwitchRate = 10, kSwitchGrace = 8;
 #define MRT_GEN_CHAIN_FENCE do { } while (0)
 #endif
 
-__global__ __launch_bounds__(kGenThreads, 4) void general_intersect_kernel(
+__global__ __launch_bounds__(kGenThreads, MRT_GEN_WAVES) void general_intersect_kernel(
     const float4* __restrict__ rays, int n_rays, const float4* __restrict__ tri_rec, int n_tri, int tris_per_slice,
     const float4* __restrict__ sph_rec, int n_sph, int sph_per_slice, const float4* __restrict__ geo,
     float t_upper, float t_lower, int t_filter_allowed, unsigned long long* __restrict__ keys,
