@@ -553,9 +553,9 @@ int mrt_png_stream_end(mrt_png_stream *s);
  * cl::Buffers in every call, CLHelpers.hpp:93-104); copies and kernels run on
  * the ctx's own stream, not on the null stream.  Results cross the link into
  * one page-locked host buffer of the ctx, as large as the largest result seen
- * (80 bytes per ray for mrt_stage_intersect, less per element for the
- * others), from which they are scattered into the caller's records; it too is
- * held until mrt_destroy.
+ * (32 bytes per ray for mrt_stage_intersect and the view rays, 16 per pixel
+ * for the shaders), from which they are scattered into the caller's records;
+ * it too is held until mrt_destroy.
  * ---------------------------------------------------------------------- */
 #pragma pack(push, 1)
 typedef struct mrt_cl_float3 { float s[4]; } mrt_cl_float3;              /* cl_float3  16 B */
