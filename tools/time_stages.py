@@ -32,6 +32,15 @@ for rep in range(3):
     col = ctx.stage_phong(xs, phong, bg, cam, lights); t.append(time.perf_counter())
     ms = [(b - a) * 1e3 for a, b in zip(t, t[1:])]
     print(f"stages {name} 400x400: uv {ms[0]:.2f} rays {ms[1]:.2f} intersect {ms[2]:.2f} phong {ms[3]:.2f} total {sum(ms):.2f} ms; intersect kernels {kms:.3f} ms", flush=True)
+# ... and with the caller's result arrays kept from call to call, as a host program holds them (a fresh
+# numpy array per call, above, pays a page fault per 4 KB the library first writes to)
+for rep in range(5):
+    t = [time.perf_counter()]
+    rays = ctx.stage_viewrays(cam, uv, focal, out=rays); t.append(time.perf_counter())
+    xs = ctx.stage_intersect(objs, rays, FLT_MAX, 0.0, out=xs); t.append(time.perf_counter())
+    col = ctx.stage_phong(xs, phong, bg, cam, lights, out=col); t.append(time.perf_counter())
+    ms = [(b - a) * 1e3 for a, b in zip(t, t[1:])]
+    print(f"stages {name} 400x400, arrays reused: rays {ms[0]:.2f} intersect {ms[1]:.2f} phong {ms[2]:.2f} ms", flush=True)
 # the device side of stage_intersect alone, warm: every (ray, object) pair in kms milliseconds
 import os  # noqa: E402
 t_lower = float(os.environ.get("MRT_TIME_STAGES_T_LOWER", "0"))
