@@ -12,7 +12,9 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize tools/filter_loop_bench.hip -o tools/filter_loop_bench
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -115,7 +117,11 @@ int run(const char* name, const float4* d_rec_plain, float* d_out, int ncu, doub
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    // filter_loop_bench MODE SECONDS: only that mode (4 or 5), again and again for that long -- for
+    // tools/sample_clocks.sh to read the clock beside it
+    const int only_mode = argc > 2 ? atoi(argv[1]) : -1;
+    const double seconds = argc > 2 ? atof(argv[2]) : 0.0;
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int ncu = prop.multiProcessorCount;
@@ -140,6 +146,14 @@ int main() {
     float4* d_rec_random;
     CHECK(hipMalloc(&d_rec_random, hr.size() * sizeof(float4)));
     CHECK(hipMemcpy(d_rec_random, hr.data(), hr.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (only_mode >= 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+            if (only_mode == 5) run<5>("random mantissas and signs", d_rec, d_out, ncu, 21.0 + 0.75, d_rec_random);
+            else run<4>("plain operands", d_rec, d_out, ncu, 21.0 + 0.75);
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("15 fma", d_rec, d_out, ncu, 15.0 + 0.2);
         run<1>("15 fma + 2 sub", d_rec, d_out, ncu, 17.0 + 0.2);
