@@ -121,6 +121,23 @@ def profiled_counters(kernel, name="teatime4k"):
     return None, None
 
 
+def profiled_clock(section="full"):
+    """Mean shader clock (GHz) over the XCDs and the samples of one section of the newest committed
+    profiles/rNN/clocks_under_load.txt (amd-smi beside a workload kept running: tools/sample_clocks.sh;
+    section "full" = MRT_FLAG_FULL_TEST frames back to back), or (None, None)."""
+    import re
+    for f in sorted((ROOT / "profiles").glob("r*/clocks_under_load.txt"), reverse=True):
+        mhz, inside = [], False
+        for line in f.read_text().splitlines():
+            if line.startswith("=="):
+                inside = line.strip() == f"== {section}"
+            elif inside and "sclk" in line:
+                mhz += [float(x) for x in re.findall(r"\b(\d{3,4})\b", line.split("sclk", 1)[1])]
+        if mhz:
+            return sum(mhz) / len(mhz) * 1e-3, str(f.relative_to(ROOT))
+    return None, None
+
+
 def profiled_traffic(c):
     """Bytes per launch that crossed the L2 -> fabric boundary (FETCH_SIZE and WRITE_SIZE are
     collected in separate --pmc runs, in KiB; on gfx950 FETCH_SIZE counts 16-byte-per-lane reads
@@ -670,6 +687,7 @@ def main():
         achieved = flops_launch / (full_trace * 1e-3) * 1e-12
         fc, fsrc = profiled_counters("mrt::full_trace_kernel") if world == 1 else (None, None)
         dc, dsrc = profiled_counters("mrt::trace_kernel") if world == 1 else (None, None)
+        clock_ghz, clock_src = profiled_clock("full")
         out = {
             "metric": "Mrays/s, teatime 3840x2160 Blinn-Phong, exact closest hit of every ray over all 4034 "
                       "primitives (default path: conservative per-pixel prefilter, reference arithmetic on survivors)",
@@ -701,6 +719,10 @@ def main():
                 "counters_source": fsrc,
                 "executed_flops_per_pair": FULL_TRACE_EXECUTED_FLOPS,
                 "frac_executed": achieved / FP32_PEAK_TFLOPS * FULL_TRACE_EXECUTED_FLOPS / FLOPS_PER_TRI_TEST,
+                # not measured in this run: amd-smi beside this kernel's frames back to back (the socket at its
+                # power limit, every XCD below the 2.4 GHz the peak is made of)
+                "clock_under_load_ghz": clock_ghz, "clock_source": clock_src,
+                "frac_of_peak_at_that_clock": (achieved / (FP32_PEAK_TFLOPS * clock_ghz / 2.4)) if clock_ghz else None,
                 "note": "MRT_FLAG_FULL_TEST kernel on the same frame in the same run: the determinants of "
                         "tri_intersect's 3x3 solve for every (ray, triangle) pair, no screen-space rejection, as a fused "
                         "conservative filter with the reference's unfused arithmetic for the survivors.  NOT a general-ray "
