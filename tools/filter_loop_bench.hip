@@ -6,7 +6,8 @@
 //   MODE 1: + W = det - Nb - Ng (two subtractions)
 //   MODE 2: + the verdict (two v_max3_f32, one v_sub, one v_or) and the or-tree / vote per record
 //   MODE 3: MODE 2 with the records in registers instead of LDS (one record, perturbed per iteration)
-//   MODE 4: MODE 2 with the kernel's LDS footprint; MODE 5: on random mantissas; MODE 6: ray after ray
+//   MODE 4: MODE 2 with the kernel's LDS footprint; MODE 5: on random mantissas; MODE 6: ray after ray;
+//   MODE 7: MODE 5 with the two multiplicands of every multiply-add exchanged
 // Prints wall time, VALU instructions per (ray, record) counted by hand, and cycles per wave
 // instruction per SIMD at an assumed 2.1 GHz (the clock under load was not measured).
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize tools/filter_loop_bench.hip -o tools/filter_loop_bench
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256, 4) void loop_bench(const float4* __restrict__ 
     float dx[kRays], dy[kRays], dz[kRays], mx[kRays], my[kRays], mz[kRays];
 #pragma unroll
     for (int s = 0; s < kRays; ++s) {
-        if (MODE == 5) {
+        if (MODE == 5 || MODE == 7) {
             // MODE 5: MODE 4 on operands with random mantissas and signs (what the arithmetic units switch per
             // instruction, hence the power they draw, depends on the bits)
             uint32_t h = (uint32_t)(tid + 256 * s + 2048 * blockIdx.x) * 2654435761u;
@@ -65,9 +66,18 @@ __global__ __launch_bounds__(256, 4) void loop_bench(const float4* __restrict__ 
             uint32_t any = 0;
 #pragma unroll
             for (int s = 0; s < kRays; ++s) {
-                const float xb = dot3(q2.x, q2.y, q2.z, mx[s], my[s], mz[s], dot3(q0.x, q0.y, q0.z, dx[s], dy[s], dz[s], q0.w));
-                const float xg = dot3(q3.x, q3.y, q3.z, mx[s], my[s], mz[s], dot3(q1.x, q1.y, q1.z, dx[s], dy[s], dz[s], q0.w));
-                const float xd = dot3(q4.x, q4.y, q4.z, dx[s], dy[s], dz[s], q1.w);
+                float xb, xg, xd;
+                if (MODE == 7) {
+                    // MODE 7: MODE 5 with the multiplicands exchanged: the ray's component (different in every lane)
+                    // is the first source operand, the record's (the same in all 64 lanes) the second
+                    xb = dot3(mx[s], my[s], mz[s], q2.x, q2.y, q2.z, dot3(dx[s], dy[s], dz[s], q0.x, q0.y, q0.z, q0.w));
+                    xg = dot3(mx[s], my[s], mz[s], q3.x, q3.y, q3.z, dot3(dx[s], dy[s], dz[s], q1.x, q1.y, q1.z, q0.w));
+                    xd = dot3(dx[s], dy[s], dz[s], q4.x, q4.y, q4.z, q1.w);
+                } else {
+                    xb = dot3(q2.x, q2.y, q2.z, mx[s], my[s], mz[s], dot3(q0.x, q0.y, q0.z, dx[s], dy[s], dz[s], q0.w));
+                    xg = dot3(q3.x, q3.y, q3.z, mx[s], my[s], mz[s], dot3(q1.x, q1.y, q1.z, dx[s], dy[s], dz[s], q0.w));
+                    xd = dot3(q4.x, q4.y, q4.z, dx[s], dy[s], dz[s], q1.w);
+                }
                 if (MODE == 0) {
                     asm volatile("" :: "v"(xb), "v"(xg), "v"(xd));
                 } else {
@@ -149,7 +159,8 @@ int main(int argc, char** argv) {
     if (only_mode >= 0) {
         const auto t0 = std::chrono::steady_clock::now();
         while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
-            if (only_mode == 5) run<5>("random mantissas and signs", d_rec, d_out, ncu, 21.0 + 0.75, d_rec_random);
+            if (only_mode == 7) run<7>("random operands, multiplicands exchanged", d_rec, d_out, ncu, 21.0 + 0.75, d_rec_random);
+            else if (only_mode == 5) run<5>("random mantissas and signs", d_rec, d_out, ncu, 21.0 + 0.75, d_rec_random);
             else run<4>("plain operands", d_rec, d_out, ncu, 21.0 + 0.75);
         }
         return 0;
@@ -162,6 +173,8 @@ int main(int argc, char** argv) {
         run<4>("... records in LDS, four waves per SIMD", d_rec, d_out, ncu, 21.0 + 0.75);
         run<5>("... the same on random mantissas and signs", d_rec, d_out, ncu, 21.0 + 0.75, d_rec_random);
         run<6>("... four waves per SIMD, ray after ray", d_rec, d_out, ncu, 21.0 + 0.75);
+        run<7>("... random operands, multiplicands exchanged", d_rec, d_out, ncu, 21.0 + 0.75, d_rec_random);
+        run<5>("... random operands, as before (again)", d_rec, d_out, ncu, 21.0 + 0.75, d_rec_random);
     }
     return 0;
 }
