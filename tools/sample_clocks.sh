@@ -2,6 +2,8 @@
 # What the GPU's shader clock and power are while each kind of work runs (amd-smi beside
 # tools/busy_loop.py, a sample every half second), and at rest.  GPU box only.
 # usage: tools/sample_clocks.sh > gpurun_out/clocks.log
+# (the last two sections need tools/filter_loop_bench, built here beforehand:
+#  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize tools/filter_loop_bench.hip -o tools/filter_loop_bench)
 cd "$(dirname "$0")/.."
 sample() {
     # socket power and the shader clock of each of the eight XCDs
