@@ -555,7 +555,10 @@ int mrt_png_stream_end(mrt_png_stream *s);
  * one page-locked host buffer of the ctx, as large as the largest result seen
  * (32 bytes per ray for mrt_stage_intersect and the view rays, 16 per pixel
  * for the shaders), from which they are scattered into the caller's records;
- * it too is held until mrt_destroy.
+ * it too is held until mrt_destroy.  The scatter runs on the calling thread,
+ * except into an array of a million elements and more or one whose pages
+ * have not been touched yet (a fresh allocation, as the reference's helpers
+ * return): then on up to eight host threads that live for that call.
  * ---------------------------------------------------------------------- */
 #pragma pack(push, 1)
 typedef struct mrt_cl_float3 { float s[4]; } mrt_cl_float3;              /* cl_float3  16 B */

@@ -81,8 +81,10 @@ def frame_rays(mrt, ctx, sc):
     return ctx.stage_viewrays(cam, ctx.stage_uv(pos, vp), focal), objs
 
 
+# (the two 400x400 cases: 160 000 elements, enough for the host to scatter the results on several threads)
 @pytest.mark.parametrize("name,n_side", [("scene_2spheres_persp_phong", 150), ("scene_gtri_ortho_phong", 150),
-                                         ("teatime", 96)])
+                                         ("teatime", 96), ("scene_2spheres_persp_phong", 400),
+                                         ("scene_gtri_ortho_flat", 400)])
 def test_stage_pipeline_matches_oracle(gpu_ctx, mrt, oracle, name, n_side):
     sc = scene_py.load_scene(SCENES / f"{name}.json")
     st = sc.struct
