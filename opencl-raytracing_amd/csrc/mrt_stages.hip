@@ -18,6 +18,8 @@
 
 #include <type_traits>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -785,6 +787,16 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
         return mrt_stage_set_error_(ctx, MRT_ERR_INVALID, "bad object array");
     if (n_rays == 0) return MRT_OK;
     static_assert(sizeof(mrt_cl_object) == 144, "object must be 144 bytes");
+#ifdef MRT_STAGE_TIMING
+    // Measurement aid: where the host's time of one call goes, to stderr.
+    using StageClock = std::chrono::steady_clock;
+    StageClock::time_point stage_t[6];
+    int stage_ti = 0;
+#define MRT_STAGE_MARK() (stage_t[stage_ti++] = StageClock::now())
+#else
+#define MRT_STAGE_MARK() do { } while (0)
+#endif
+    MRT_STAGE_MARK();
     // One upload for everything the kernels read about the objects: the exact records in the
     // caller's order, the object indices of the triangles, the sphere records, and six zeroed
     // words for the ray bounds.  Sections start on 256-byte boundaries.
@@ -822,6 +834,7 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
             ++is;
         }
     }
+    MRT_STAGE_MARK();                                   // the object pack is built
     hipStream_t stage_stream = (hipStream_t)mrt_ctx_stream_(ctx);
     DevBuf d_pack, d_rays, d_out, d_rec, d_keys;
     STAGE_BUF(d_pack, 0, pack_bytes);
@@ -839,6 +852,7 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
     uint32_t* d_bounds = reinterpret_cast<uint32_t*>(dp + off_bounds);
     STAGE_COPY(d_pack.p, pack.data(), pack_bytes, hipMemcpyHostToDevice);
     STAGE_COPY(d_rays.p, rays, (size_t)n_rays * 32, hipMemcpyHostToDevice);
+    MRT_STAGE_MARK();                                   // pack and rays handed to the runtime
 
     // The object list in slices (grid layers), so that a call with few rays still fills the GPU.
     // The GPU holds kResidentBlocks blocks at a time (four per compute unit: four waves per SIMD);
@@ -893,9 +907,11 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
                        (mrt::HitOut*)d_out.p);
     STAGE_TRY(hipGetLastError());
     STAGE_TRY(hipEventRecord(ev1, stage_stream));
+    MRT_STAGE_MARK();                                   // kernels enqueued
     const mrt::HitOut* res = static_cast<const mrt::HitOut*>(mrt_stage_host_buffer_(ctx, out_bytes + sizeof(mrt::HitOut)));
     if (!res) return MRT_ERR_HIP;
     STAGE_COPY(const_cast<mrt::HitOut*>(res), d_out.p, out_bytes + sizeof(mrt::HitOut), hipMemcpyDeviceToHost);
+    MRT_STAGE_MARK();                                   // results in page-locked host memory
     {
         uint32_t switched = 0;
         std::memcpy(&switched, res + n_rays, sizeof switched);
@@ -929,6 +945,15 @@ int mrt_stage_intersect(mrt_ctx* ctx, const mrt_cl_object* objects, int n_object
             }
         }
     });
+    MRT_STAGE_MARK();                                   // ... and in the caller's records
+#ifdef MRT_STAGE_TIMING
+    {
+        auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(stage_t[b] - stage_t[a]).count(); };
+        std::fprintf(stderr, "stage_intersect host: pack %.0f, uploads %.0f, launches %.0f, wait + download %.0f (kernels %.0f), scatter %.0f us\n",
+                     us(0, 1), us(1, 2), us(2, 3), us(3, 4), kernel_ms * 1e3, us(4, 5));
+    }
+#endif
+#undef MRT_STAGE_MARK
     return MRT_OK;
 } MRT_GUARD((void)mrt_stage_set_error_(ctx, code_, what_))
 
