@@ -104,6 +104,10 @@ def test_stage_pipeline_matches_oracle(gpu_ctx, mrt, oracle, name, n_side):
     xs_o, ids_o = oracle.stage_intersect(objs, rays_o, FLT_MAX, 0.0)
     assert (ids_o >= 0).any()
     same_records(xs_g, xs_o)
+    # ... and into an array whose pages are resident (the call above got a fresh one: the library
+    # fills an untouched array of this size on several host threads, a resident one on the caller's)
+    same_records(gpu_ctx.stage_intersect(objs, rays_g, FLT_MAX, 0.0, out=xs_g.copy()), xs_o)
+    same_records(gpu_ctx.stage_viewrays(cam, uv_g, focal, out=rays_g.copy()), rays_o)
 
     bg = tuple(st.background) + (0.5,)
     flat_g = gpu_ctx.stage_flat(xs_g, bg)
