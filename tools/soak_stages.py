@@ -23,6 +23,7 @@ ctx = mrt.Context(device=0)
 FLT_MAX = float(np.finfo(np.float32).max)
 bad = 0
 pairs = 0
+switched = 0          # calls in which at least one wave took up the filter with the fourth determinant
 t0 = time.time()
 for it in range(n_cases):
     span = float(10.0 ** rng.uniform(-3, 4))
@@ -44,6 +45,7 @@ for it in range(n_cases):
         lo = float(rng.choice([0.0, 0.0, -1.0 * span, 0.25 * span, -np.inf]))
         hi = float(rng.choice([FLT_MAX, FLT_MAX, np.inf, 2.0 * span, 0.5 * span]))
         g = ctx.stage_intersect(objs, rays, hi, lo)
+        switched += 1 if ctx.stage_t_switches() else 0
         o, _ = oracle_py.stage_intersect(objs, rays, hi, lo)
         pairs += len(objs) * n_rays
         try:
@@ -54,5 +56,5 @@ for it in range(n_cases):
     if it % 20 == 0:
         print(f"case {it}: span {span:.3g}, {n_tri} triangles, {n_sph} spheres, {n_rays} rays; {pairs:.3g} pairs so far, {time.time() - t0:.0f} s", flush=True)
 ctx.close()
-print(f"cases: {n_cases} pairs: {pairs} mismatches: {bad}")
+print(f"cases: {n_cases} pairs: {pairs} calls with waves that switched filters: {switched} mismatches: {bad}")
 sys.exit(1 if bad else 0)
