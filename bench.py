@@ -446,7 +446,7 @@ def general_ray(env, reps=12):
     from test_gpu_stages import make_inputs
     mrt = env.mrt
     sc = scene_py.load_scene(ROOT / "scenes" / "teatime.json")
-    pos, vp, cam, objs, _, _ = make_inputs(mrt, sc, 400)
+    pos, vp, cam, objs, lights, phong = make_inputs(mrt, sc, 400)
     ctx = mrt.Context(device=env.dev_index)
     try:
         rays = ctx.stage_viewrays(cam, ctx.stage_uv(pos, vp), sc.struct.focal)
@@ -481,6 +481,26 @@ def general_ray(env, reps=12):
         finally:
             warm.close()
         warm_ms.sort()
+        # The whole calls, copies and host work included, as the reference's render() makes them
+        # (gfxraytrace.hpp:857-944): into a fresh result array per call, as its helpers return one
+        # (CLHelpers.hpp:91-293), and into arrays kept from frame to frame.  Best of five frames.
+        import time as _time
+        bg = tuple(sc.struct.background) + (1.0,)
+        calls = {}
+        for label, keep in (("fresh_arrays", False), ("arrays_kept", True)):
+            best = None
+            r_out = x_out = c_out = None
+            for _ in range(6):
+                t = [_time.perf_counter()]
+                uv = ctx.stage_uv(pos, vp); t.append(_time.perf_counter())
+                r_out = ctx.stage_viewrays(cam, uv, sc.struct.focal, out=r_out if keep else None); t.append(_time.perf_counter())
+                x_out = ctx.stage_intersect(objs, r_out, flt_max, 0.0, out=x_out if keep else None); t.append(_time.perf_counter())
+                c_out = ctx.stage_phong(x_out, phong, bg, cam, lights, out=c_out if keep else None); t.append(_time.perf_counter())
+                ms4 = [(b - a) * 1e3 for a, b in zip(t, t[1:])]
+                if best is None or sum(ms4) < sum(best):
+                    best = ms4
+            calls[label] = {"uv_ms": best[0], "rays_ms": best[1], "intersect_ms": best[2], "phong_ms": best[3],
+                            "frame_ms": sum(best)}
         # ... and on the benchmark frame's own rays: 3840 x 2160 of them as an array (265 MB in, 663 MB
         # of hit records out: the call takes a second, its kernels are what is timed)
         big_rays, big_objs = frame_rays(mrt, ctx, big_scene)
@@ -510,6 +530,7 @@ def general_ray(env, reps=12):
             "counters_source": gsrc,
             "kernel": "general_intersect_kernel (+ ray bounds, records, finish: every kernel of one mrt_stage_intersect call)",
             "rays": len(rays), "objects": len(objs), "kernel_ms": med, "best_kernel_ms": ms[0],
+            "stage_calls_400x400": calls,
             "kernel_ms_behind_other_work": warm_ms[len(warm_ms) // 2],
             "frac_behind_other_work": flops / (warm_ms[len(warm_ms) // 2] * 1e-3) * 1e-12 / FP32_PEAK_TFLOPS,
             "prim_tests_per_s": len(rays) * len(objs) / (med * 1e-3),
