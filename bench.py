@@ -138,6 +138,48 @@ def profiled_clock(section="full"):
     return None, None
 
 
+def clock_under_load(env, job, seconds=2.0):
+    """Socket power and mean shader clock over the XCDs while `job`'s frames run back to back for
+    `seconds`: amd-smi in a child process, again and again, beside the frames.  The first sample is
+    dropped (taken while the clock settles).  None where amd-smi is missing or says nothing."""
+    import re
+    import subprocess
+    import threading
+    import torch
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                r = subprocess.run(["amd-smi", "metric", "-g", str(env.dev_index), "--clock", "--power"],
+                                   capture_output=True, text=True, timeout=10)
+            except Exception:                         # noqa: BLE001
+                return
+            mhz = [float(x) for x in re.findall(r"GFX_\d+:\s*\n\s*CLK:\s*(\d+)\s*MHz", r.stdout)]
+            watts = re.search(r"SOCKET_POWER:\s*(\d+)\s*W", r.stdout)
+            if mhz:
+                samples.append((sum(mhz) / len(mhz) * 1e-3, min(mhz) * 1e-3, max(mhz) * 1e-3,
+                                float(watts.group(1)) if watts else None))
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t_end, k = time.perf_counter() + seconds, 0
+    while time.perf_counter() < t_end:
+        for _ in range(4):
+            job.step(k)
+            k += 1
+        torch.cuda.synchronize(env.dev)
+    stop.set()
+    th.join(timeout=15)
+    use = samples[1:] if len(samples) > 1 else samples
+    if not use:
+        return None
+    watts = [w for _, _, _, w in use if w is not None]
+    return {"ghz": sum(g for g, _, _, _ in use) / len(use), "slowest_xcd_ghz": min(lo for _, lo, _, _ in use),
+            "fastest_xcd_ghz": max(hi for _, _, hi, _ in use), "socket_watts": sum(watts) / len(watts) if watts else None,
+            "samples": len(use), "frames": k}
+
+
 def profiled_traffic(c):
     """Bytes per launch that crossed the L2 -> fabric boundary (FETCH_SIZE and WRITE_SIZE are
     collected in separate --pmc runs, in KiB; on gfx950 FETCH_SIZE counts 16-byte-per-lane reads
@@ -696,6 +738,13 @@ def main():
     full_elapsed = fjob.timed(full_reps, 1)
     full_trace, _ = fjob.kernel_ms(full_reps)
     full_rows = fjob.rows
+    # ... and what the chip runs at under that kernel, here and now (one GPU: amd-smi's index is the HIP ordinal)
+    live_clock = None
+    if world == 1 and rank == 0:
+        try:
+            live_clock = clock_under_load(env, fjob)
+        except Exception:                             # noqa: BLE001 -- an extra: never the run's JSON line
+            live_clock = None
     fjob.close()
 
     out = None
@@ -740,10 +789,13 @@ def main():
                 "counters_source": fsrc,
                 "executed_flops_per_pair": FULL_TRACE_EXECUTED_FLOPS,
                 "frac_executed": achieved / FP32_PEAK_TFLOPS * FULL_TRACE_EXECUTED_FLOPS / FLOPS_PER_TRI_TEST,
-                # not measured in this run: amd-smi beside this kernel's frames back to back (the socket at its
-                # power limit, every XCD below the 2.4 GHz the peak is made of)
-                "clock_under_load_ghz": clock_ghz, "clock_source": clock_src,
-                "frac_of_peak_at_that_clock": (achieved / (FP32_PEAK_TFLOPS * clock_ghz / 2.4)) if clock_ghz else None,
+                # amd-smi beside this kernel's frames back to back, in this run (the socket at its power limit,
+                # every XCD below the 2.4 GHz the peak is made of); where amd-smi says nothing, the committed sample
+                "clock_under_load": live_clock,
+                "clock_under_load_ghz": live_clock["ghz"] if live_clock else clock_ghz,
+                "clock_source": "amd-smi in this run" if live_clock else clock_src,
+                "frac_of_peak_at_that_clock": (achieved / (FP32_PEAK_TFLOPS * (live_clock["ghz"] if live_clock else clock_ghz) / 2.4))
+                if (live_clock or clock_ghz) else None,
                 "note": "MRT_FLAG_FULL_TEST kernel on the same frame in the same run: the determinants of "
                         "tri_intersect's 3x3 solve for every (ray, triangle) pair, no screen-space rejection, as a fused "
                         "conservative filter with the reference's unfused arithmetic for the survivors.  NOT a general-ray "
