@@ -740,7 +740,9 @@ def main():
     full_rows = fjob.rows
     # ... and what the chip runs at under that kernel, here and now (one GPU: amd-smi's index is the HIP ordinal)
     live_clock = None
-    if world == 1 and rank == 0:
+    # (not under a profiler, whose preloaded library every child process would inherit)
+    profiled = any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY"))
+    if world == 1 and rank == 0 and not profiled:
         try:
             live_clock = clock_under_load(env, fjob)
         except Exception:                             # noqa: BLE001 -- an extra: never the run's JSON line
